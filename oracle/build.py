@@ -1,0 +1,26 @@
+"""Build the C part of the oracle: oracle/_build/libvq_oracle.so (gcc, no GPU needed).
+
+There is no oracle/_ref: the reference is pure Python (no C/C++ sources to compile), so
+the restatement is pinned by fixtures generated from the importable reference modules
+(tests/golden/make_golden.py) instead.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libvq_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(HERE, "vq_oracle.c")
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(src):
+        return LIB
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC",
+                           "-o", LIB, src, "-lm"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,189 @@
+"""Generate golden vectors from the importable parts of the reference (build container only).
+
+Run once here:  python tests/golden/make_golden.py
+It loads /root/reference/models/{models,bottleneck,embed}.py by FILE PATH (the package
+`models` itself cannot be imported: models/__init__.py eagerly imports families whose
+third-party deps -- timm, vjepa2, flash_attn, easydict -- are not installed),
+feeds them inputs from oracle/inputs.py (so only OUTPUTS need committing) and writes
+small .npz fixtures next to this file.  /root/reference does not exist on the GPU box;
+tests only read the committed .npz files.
+
+`models/embed.py` does `from timm.models.vision_transformer import PatchEmbed` for a class
+(`VideoPatchEmbed`) that the hot path never instantiates (temporal_patch_size > 1); a
+one-symbol placeholder satisfies that import line so the numpy sin-cos builders and
+PatchEmbed3D (plain nn.Conv3d) can run.  Nothing of timm's behaviour is emulated.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import inputs as gen  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    models = _load("models", os.path.join(REF, "models/models.py"))
+    bott = _load("models.bottleneck", os.path.join(REF, "models/bottleneck.py"))
+    if "timm" not in sys.modules:
+        timm = types.ModuleType("timm")
+        tm = types.ModuleType("timm.models")
+        tv = types.ModuleType("timm.models.vision_transformer")
+        tv.PatchEmbed = type("PatchEmbed", (torch.nn.Module,), {})
+        timm.models = tm
+        tm.vision_transformer = tv
+        sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.vision_transformer": tv})
+    emb = _load("models.embed", os.path.join(REF, "models/embed.py"))
+    return models, bott, emb
+
+
+def checksum(a):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    w = (np.arange(a.size, dtype=np.float64) % 97.0) + 1.0
+    return np.array([a.sum(), np.abs(a).sum(), (a * w).sum()], dtype=np.float64)
+
+
+def vq_cases():
+    # (N tokens as (B, n)), K, d, seed
+    return [((2, 128), 1024, 24, 101), ((1, 1024), 8192, 24, 102), ((2, 256), 8192, 16, 103)]
+
+
+def make_vq(models, out):
+    for (b, n), K, d, seed in vq_cases():
+        W = gen.kaiming_uniform_codebook(K, d, seed)
+        z = gen.normal((b, n, d), seed + 1000)
+        g_rz = gen.normal((b, n, d), seed + 2000)
+        for mode in ("L", "D"):
+            spec = {"name": "vq", "args": dict(dim=d, codebook_size=K, commitment_loss_weight=0.25,
+                                               codebook_loss_weight=1.0, entropy_loss_weight=0.0,
+                                               entropy_loss_temperature=0.01, l2_normalized=True,
+                                               stochastic=(mode == "D"), stochastic_temperature=0.03)}
+            vq = models.make(spec)
+            with torch.no_grad():
+                vq.embedding.weight.copy_(torch.from_numpy(W))
+            if mode == "D":
+                vq.eval()
+                vq.set_eval_deterministic(True)
+            zt = torch.from_numpy(z).clone().requires_grad_(True)
+            o = vq(zt)
+            # scalar with a fixed upstream gradient on regularized_z and weight 0.7 on loss_q
+            (o["regularized_z"] * torch.from_numpy(g_rz)).sum().add(0.7 * o["loss_q"]).backward()
+            # top-1 / top-2 margins so near-ties are visible to the test
+            with torch.no_grad():
+                zn = torch.nn.functional.normalize(torch.from_numpy(z).reshape(-1, d), dim=-1)
+                en = torch.nn.functional.normalize(torch.from_numpy(W), dim=-1)
+                top2 = (zn.double() @ en.double().t()).topk(2, dim=-1).values
+                margin = (top2[:, 0] - top2[:, 1]).numpy()
+            key = f"vq_N{b * n}_K{K}_d{d}_{mode}"
+            np.savez_compressed(
+                os.path.join(out, key + ".npz"),
+                idx=o["bottleneck_rep"].numpy().astype(np.int32),
+                loss_commit=np.float32(o["loss_commit"].item()), loss_codebook=np.float32(o["loss_codebook"].item()),
+                loss_q=np.float32(o["loss_q"].item()),
+                regularized_z=o["regularized_z"].detach().numpy(),
+                unregularized_z=o["unregularized_z"].detach().numpy(),
+                dz=zt.grad.numpy(), dE=vq.embedding.weight.grad.numpy(),
+                margin=margin.astype(np.float64),
+                meta=np.array([b, n, K, d, seed], dtype=np.int64))
+            print(key, "idx[:6]", o["bottleneck_rep"].reshape(-1)[:6].tolist(), "min margin", margin.min())
+
+
+def make_bottleneck(models, out):
+    b, n, D, d, K, seed = 2, 64, 768, 24, 1024, 201
+    spec = {"name": "bottleneck", "args": {"bottleneck_dim": d, "norm": "none", "regularizer": {
+        "name": "vq", "args": dict(codebook_size=K, commitment_loss_weight=0.25, codebook_loss_weight=1.0,
+                                   entropy_loss_weight=0.0, entropy_loss_temperature=0.01, l2_normalized=True,
+                                   stochastic=False, stochastic_temperature=0.03)}}}
+    bt = models.make(spec, args={"token_nums": n, "input_dim": D, "output_dim": D})
+    w_in, b_in = gen.xavier_uniform((d, D), seed + 1), gen.uniform((d,), seed + 2, -0.02, 0.02)
+    w_out, b_out = gen.xavier_uniform((D, d), seed + 3), gen.uniform((D,), seed + 4, -0.02, 0.02)
+    W = gen.kaiming_uniform_codebook(K, d, seed + 5)
+    with torch.no_grad():
+        bt.in_linear.weight.copy_(torch.from_numpy(w_in)); bt.in_linear.bias.copy_(torch.from_numpy(b_in))
+        bt.out_linear.weight.copy_(torch.from_numpy(w_out)); bt.out_linear.bias.copy_(torch.from_numpy(b_out))
+        bt.regularizer.embedding.weight.copy_(torch.from_numpy(W))
+    x = torch.from_numpy(gen.normal((b, n, D), seed + 6)).requires_grad_(True)
+    g = torch.from_numpy(gen.normal((b, n, D), seed + 7))
+    o = bt(x)
+    (o["output"] * g).sum().add(0.7 * o["loss_q"]).backward()
+    np.savez_compressed(
+        os.path.join(out, "bottleneck_small.npz"),
+        keys=np.array(sorted(o.keys())),
+        output=o["output"].detach().numpy(), idx=o["bottleneck_rep"].numpy().astype(np.int32),
+        projected_z=o["projected_z"].detach().numpy(),
+        input_norm_first=np.float32(o["input_norm_first"]), input_norm_last=np.float32(o["input_norm_last"]),
+        loss_q=np.float32(o["loss_q"].item()),
+        dx=x.grad.numpy(), dW_in=bt.in_linear.weight.grad.numpy(), db_in=bt.in_linear.bias.grad.numpy(),
+        dW_out=bt.out_linear.weight.grad.numpy(), db_out=bt.out_linear.bias.grad.numpy(),
+        dE=bt.regularizer.embedding.weight.grad.numpy(),
+        meta=np.array([b, n, D, d, K, seed], dtype=np.int64))
+    print("bottleneck keys", sorted(o.keys()))
+    # decode path (bottleneck.py:166-168, 327-344)
+    ids = torch.from_numpy((gen.hash_u64(b * n, seed + 8) % np.uint64(K)).astype(np.int64)).reshape(b, n)
+    with torch.no_grad():
+        dec = bt.decode(ids)
+    np.savez_compressed(os.path.join(out, "bottleneck_decode.npz"), ids=ids.numpy().astype(np.int32), out=dec.numpy())
+
+
+def make_embed(emb, out):
+    res = {}
+    for (pt, p, T, S, B, seed) in [(2, 16, 2, 64, 1, 301), (4, 8, 4, 64, 1, 302), (2, 16, 16, 128, 1, 303), (4, 8, 16, 128, 1, 304)]:
+        m = emb.PatchEmbed3D(S, T, p, pt, 3, 768, bias=True)
+        w = gen.xavier_uniform((768, 3, pt, p, p), seed + 1)
+        bb = gen.uniform((768,), seed + 2, -0.02, 0.02)
+        with torch.no_grad():
+            m.proj.weight.copy_(torch.from_numpy(w)); m.proj.bias.copy_(torch.from_numpy(bb))
+        x = torch.from_numpy(gen.video_clips(B, T, S, seed + 3))
+        with torch.no_grad():
+            y = m(x).numpy()
+        tag = f"pe3d_pt{pt}_p{p}_T{T}_S{S}"
+        res[tag + "_shape"] = np.array(y.shape)
+        res[tag + "_sum"] = checksum(y)
+        res[tag + "_rows"] = y[0, :: max(1, y.shape[1] // 16)][:16].copy()
+        res[tag + "_meta"] = np.array([pt, p, T, S, B, seed])
+        print(tag, y.shape, checksum(y))
+    np.savez_compressed(os.path.join(out, "patch_embed3d.npz"), **res)
+    res = {}
+    for gs in (4, 8, 16):
+        for fn in (1, 4, 8):
+            t = emb.get_3d_sincos_pos_embed(768, gs, fn)
+            tag = f"sincos3d_g{gs}_f{fn}"
+            res[tag + "_sum"] = checksum(t)
+            if t.shape[0] <= 64:
+                res[tag + "_full"] = t.astype(np.float32)
+            else:
+                res[tag + "_rows"] = t[:: t.shape[0] // 32][:32].astype(np.float32)
+    for n, sc in ((1024, 10000), (512, 10000), (56, 10000), (64, 100)):
+        t = emb.get_1d_sincos_pos_embed_from_grid(768, np.arange(n), sc)
+        res[f"sincos1d_n{n}_s{sc}_sum"] = checksum(t)
+        res[f"sincos1d_n{n}_s{sc}_rows"] = t[:: max(1, n // 16)][:16].astype(np.float32)
+    np.savez_compressed(os.path.join(out, "sincos.npz"), **res)
+    print("sincos fixtures:", len(res))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    models, bott, emb = load_reference()
+    make_vq(models, HERE)
+    make_bottleneck(models, HERE)
+    make_embed(emb, HERE)
+    print("done; sizes:")
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
