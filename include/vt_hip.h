@@ -1,0 +1,265 @@
+/* vt_hip.h -- C ABI of libvt_hip.so: the MI355X (gfx950) kernels behind the LARP tokenizer's
+ * encode -> quantize -> decode training step.
+ *
+ * The reference (zhxie0117/video-tokenizer) is pure Python and has NO FFI of its own: the path
+ * sits behind its model registry (models/models.py:8-27) and runs torch / timm library ops.
+ * This header is the boundary the build introduces beneath those Python classes; each entry
+ * point names the reference line whose arithmetic it replaces.  The Python side that binds
+ * it (ctypes, tensor.data_ptr(), torch.cuda.current_stream().cuda_stream) is in
+ * video-tokenizer_amd/hip.py; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - every function enqueues work on `stream` (a hipStream_t) and returns immediately;
+ *     nothing here allocates, frees or synchronises (hipGraph-capturable).
+ *   - the caller owns every buffer (outputs, saved-for-backward, workspaces); sizes come
+ *     from the matching *_workspace_bytes().
+ *   - return 0 on success, <0 on error; vt_last_error() gives the thread-local message.
+ *   - "bf16" buffers are raw 16-bit bfloat16; `void*` is used for them in signatures.
+ */
+#ifndef VT_HIP_H
+#define VT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vtStream; /* hipStream_t */
+
+enum { VT_OK = 0, VT_ERR_INVALID = -1, VT_ERR_LAUNCH = -2, VT_ERR_UNSUPPORTED = -3 };
+
+int vt_abi_version(void);
+int vt_last_error(char* buf, size_t n);
+
+/* row r of a logical [rows, dim] operand lives at physical row
+ *   (r / grp) * stride + off + (r % grp)        (grp == 0: identity)
+ * Used to read/write a slice "rows off..off+grp of every sequence of length stride" in place,
+ * e.g. the last len(query) tokens that TransformerEncoderParallel keeps (transformer.py:69). */
+typedef struct {
+    int32_t grp;
+    int64_t stride;
+    int64_t off;
+} vtRowMap;
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM "NT": C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate on MFMA.
+ * Replaces nn.Linear / F.linear under autocast(bf16): timm Block's qkv/proj/fc1/fc2
+ * (models/transformer.py:52-59), Bottleneck.in_linear/out_linear (models/bottleneck.py:109-110,
+ * 142,163), OutputLayer.linear (models/larp_tokenizer.py:35,40) and the Conv3d of PatchEmbed3D
+ * seen as a GEMM over gathered patches (models/embed.py:82,110), plus their input gradients.
+ * K must be a multiple of 64; M and N are arbitrary (edge tiles are clamped on load, masked on
+ * store).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    VT_EPI_BF16 = 0,       /* out(bf16) = acc [+ bias]                                        */
+    VT_EPI_BF16_GELU = 1,  /* out(bf16) = u = acc + bias ; out2(bf16) = gelu_erf(u)           */
+    VT_EPI_F32 = 2,        /* out(f32)  = [round_bf16](acc [+ bias]) [+ residual] [+ rowmod]; */
+                           /*             optional out2(bf16) copy; optional output row map   */
+    VT_EPI_BF16_DGELU = 3  /* out(bf16) = acc * gelu_erf'(aux)      (aux = saved u, bf16)     */
+};
+
+typedef struct {
+    const void* A; int64_t lda; /* bf16 [M,K] */
+    const void* B; int64_t ldb; /* bf16 [N,K] */
+    int32_t M, N, K;
+    int32_t epi;
+    void* out; int64_t ldo;
+    void* out2; int64_t ldo2;
+    const float* bias;                       /* [N] or NULL                                   */
+    const float* residual; int64_t ldr;      /* f32, indexed like `out` (after the row map)   */
+    const float* rowmod; int32_t rowmod_period; /* f32 [period,N] added at row (r % period)   */
+    const void* aux; int64_t ldaux;          /* bf16 [M,N]                                    */
+    vtRowMap omap;                           /* VT_EPI_F32 only                               */
+    int32_t round_bf16;                      /* VT_EPI_F32 only                               */
+} vtGemmNT;
+
+int vt_gemm_nt(const vtGemmNT* p_host, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM "TN", grouped: for each problem g  C_g[P,Q] = A_g[M,P]^T . B_g[M,Q]  (fp32 out).
+ * Weight gradients dW = dY^T X of every nn.Linear / the Conv3d above (what autograd derives
+ * for F.linear); all problems of one launch share one grid so a transformer block's four
+ * weight gradients fill the chip without split-K or atomics.  M % 64 == 0, P % 8 == 0,
+ * Q % 8 == 0; rows >= p_lim and cols >= q_lim of C are not stored; row_perm (optional,
+ * int32[p_lim]) scatters row p of C to row row_perm[p].  At most VT_TN_MAX_GROUP problems.
+ * ------------------------------------------------------------------------------------------ */
+#define VT_TN_MAX_GROUP 8
+typedef struct {
+    const void* A; int64_t lda; /* bf16 [M,P]  (dY) */
+    const void* B; int64_t ldb; /* bf16 [M,Q]  (X)  */
+    int32_t M, P, Q;
+    float* out; int64_t ldo;
+    int32_t p_lim, q_lim;
+    const int32_t* row_perm;
+} vtGemmTN;
+
+int vt_gemm_tn_grouped(const vtGemmTN* problems_host, int32_t n_problems, vtStream stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (fp32 in, fp32 statistics, bf16 out for the next MFMA GEMM).
+ * Replaces nn.LayerNorm inside timm Block (norm1/norm2, eps 1e-5; models/transformer.py:52-59)
+ * and OutputLayer.norm_final (eps 1e-6; models/larp_tokenizer.py:34,39), forward and backward.
+ * dim in {256,512,768,1024}.  Row r of x/dres/dx/dx_bf16 is at physical row xmap(r); y, dy, mean,
+ * rstd are indexed by r.  Backward also adds the residual-stream gradient `dres` (may be NULL)
+ * and emits column sums: dgamma, dbeta and (optional) dxsum = sum_r dx[r,:] (the bias gradient
+ * of the Linear that produced this residual stream).
+ * ------------------------------------------------------------------------------------------ */
+int vt_layernorm_fwd(const float* x, vtRowMap xmap, const float* gamma, const float* beta, float eps, int64_t rows,
+                     int32_t dim, void* y_bf16, float* mean, float* rstd, vtStream stream);
+size_t vt_layernorm_bwd_workspace_bytes(int32_t dim);
+int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xmap, const float* gamma, const float* mean,
+                     const float* rstd, const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16,
+                     float* dgamma, float* dbeta, float* dxsum, void* workspace, vtStream stream);
+
+/* column sums out[c] = sum_r src[map(r), c] (bias gradients of nn.Linear); src bf16 or fp32 */
+size_t vt_colsum_workspace_bytes(int32_t width);
+int vt_colsum(const void* src, int32_t src_is_bf16, int64_t ld, vtRowMap map, int64_t rows, int32_t width, float* out,
+              void* workspace, vtStream stream);
+/* out[j,:] = sum_b src[map(b*n + j), :]  -- gradient of encoder_latent_query_embed, which
+ * larp_tokenizer.py:410 broadcasts over the batch with .repeat(b,1,1) */
+int vt_batch_sum(const float* src, vtRowMap map, int32_t batch, int32_t n, int32_t dim, float* out, vtStream stream);
+/* dst[r,:] = bf16(src[map(r),:]) */
+int vt_cast_rows(const float* src, vtRowMap map, int64_t rows, int32_t dim, void* dst_bf16, int64_t ldd, vtStream stream);
+/* dst[b*seq + off + j, :] = src[b*n + j, :] + table[j, :] + vec[:]   (each term optional)
+ * sequence assembly: torch.cat([context, query]) of transformer.py:64 without a copy kernel per
+ * operand, `z + decoder_latent_pe` (larp_tokenizer.py:463-464) and the query-embed broadcasts
+ * (:410, :465). */
+int vt_assemble_rows(float* dst, int64_t seq, int64_t off, int32_t batch, int32_t n, int32_t dim, const float* src,
+                     const float* table, const float* vec, vtStream stream);
+/* fp32 master weight W[N,K] -> bf16 W[N,ldd] and/or bf16 W^T[K,lddT]; packed row r = W[row_perm[r]] */
+int vt_pack_weight(const float* w, int32_t N, int32_t K, const int32_t* row_perm, void* wb, int64_t ldd, void* wt,
+                   int64_t lddT, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (T,H,W) patchify / unpatchify.  Patch-row columns are in (c,dt,dy,dx) order == Conv3d weight
+ * flattening (models/embed.py:82,110-112); unpatchify is the inverse and, with the head weight
+ * rows permuted at pack time, replaces LARPTokenizer.unpatchify's einops permute + .contiguous()
+ * (models/larp_tokenizer.py:441-454,493).  p % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int vt_patchify(const float* video, int32_t B, int32_t C, int32_t T, int32_t S, int32_t pt, int32_t p, void* rows_bf16,
+                vtStream stream);
+int vt_unpatchify(const float* rows, int32_t B, int32_t C, int32_t T, int32_t S, int32_t pt, int32_t p, float* video,
+                  vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention, head_dim 64, no mask (timm Attention -> F.scaled_dot_product_attention inside
+ * timm Block, models/transformer.py:52-59).  qkv bf16 [B,L,3,H,64]; o/dO bf16 [B,L,H,64];
+ * lse2 fp32 [B,H,L] (log2-domain LSE of the scaled scores, saved for backward);
+ * delta_ws fp32 [B,H,L] scratch.  Any L >= 1 (tail rows/keys are masked).
+ * ------------------------------------------------------------------------------------------ */
+int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream);
+int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
+                     int32_t hd, void* dqkv, float* delta_ws, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vector quantisation (SimpleVectorQuantizer.forward, models/bottleneck.py:262-324).
+ *   mode 0: stochastic=False  argmin(|z|^2+|e|^2-2z.e)           (:282-290)
+ *   mode 1: eval-deterministic argmax(softmax(z.e/tau))           (:275-278)
+ *   mode 2: training default   multinomial(softmax(z.e/tau))      (:280)  via Gumbel-max, counter RNG
+ * z_in fp32 [N,ldz]; codebook fp32 [K,d] (nn.Embedding weight); d in {8,16,24,32}.
+ * Outputs (all caller-owned, saved for backward): E [K,d] = normalised codebook ('emb'), wnorm [K],
+ * zn [N,d] ('unregularized_z'), znorm [N], idx int64 [N] ('bottleneck_rep'), rz fp32 [N,d]
+ * ('regularized_z' = z + (q - z)), optional rz_pad bf16 [N,ldp] (cols >= d untouched),
+ * losses[4] = {loss_q, loss_commit, loss_codebook, mse}.  Index arithmetic is bit-exact against
+ * oracle/vq_oracle.c (sequential fp32 FMA chain; lowest index wins ties).
+ * Backward: gscal = device {dL/dloss_q, dL/dloss_commit, dL/dloss_codebook} (may be NULL);
+ * g_rz = dL/dregularized_z fp32 [N,ldg] (may be NULL); outputs dz_in (fp32 [N,d] and/or bf16
+ * [N,ldp]) and the dense codebook gradient dW [K,d] (deterministic, no atomics).
+ * ------------------------------------------------------------------------------------------ */
+size_t vt_vq_workspace_bytes(int32_t N, int32_t K, int32_t d);
+int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
+                  int32_t l2_normalized, float inv_tau, float beta, float codebook_w, uint64_t seed, float* E, float* wnorm,
+                  float* zn, float* znorm, int64_t* idx, float* rz, void* rz_pad_bf16, int64_t ldp, float* losses,
+                  void* workspace, vtStream stream);
+int vt_vq_backward(const float* g_rz, int64_t ldg, const float* gscal, float beta, float codebook_w, const float* zn,
+                   const float* znorm, const float* E, const float* wnorm, const int64_t* idx, int32_t N, int32_t K,
+                   int32_t d, int32_t l2_normalized, float* dz_in, void* dz_pad_bf16, int64_t ldp, float* dW,
+                   vtStream stream);
+/* get_codebook_entry (bottleneck.py:327-344): E = normalise(codebook) then out[n,:] = E[idx[n],:] */
+int vt_vq_prep_codebook(const float* codebook, int32_t K, int32_t d, int32_t l2_normalized, float* E, float* wnorm,
+                        void* workspace, vtStream stream);
+int vt_vq_gather(const float* E, const int64_t* idx, int32_t N, int32_t K, int32_t d, float* out, void* out_pad_bf16,
+                 int64_t ldp, vtStream stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-model engine: LARPTokenizer.forward = encode -> bottleneck(VQ) -> decode
+ * (models/larp_tokenizer.py:400-428, 456-469, 489-496; TransformerEncoderParallel.forward
+ * models/transformer.py:62-70; Bottleneck.forward models/bottleneck.py:170-188) and the backward
+ * autograd derives for it, as ONE enqueue per direction (no per-op host work; hipGraph-capturable).
+ * Mixed precision follows torch.autocast(bf16) on the reference: fp32 parameters, residual stream,
+ * LayerNorm statistics, VQ and pixels; bf16 MFMA operands with fp32 accumulation.
+ *
+ * The caller owns: parameters/gradients (fp32, reference state-dict layout), one workspace of
+ * vt_tokenizer_workspace_bytes() (zeroed once by vt_tokenizer_init_workspace), and the outputs.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t B, C, T, S, pt, p;            /* batch per GPU, channels, frames, side, patch sizes      */
+    int32_t D, H, depth_enc, depth_dec;   /* hidden (768), heads (12 => head_dim 64), block counts   */
+    int32_t Nq, d, K;                     /* bottleneck_token_num, bottleneck_dim, codebook_size     */
+    int32_t vq_mode, l2_normalized;       /* 0 l2-argmin | 1 cos-argmax | 2 cos-sample               */
+    float inv_tau, beta, codebook_w;      /* 1/stochastic_temperature, commitment / codebook weights */
+} vtTokenizerConfig;
+
+typedef struct {                          /* one timm Block; same struct (non-const use) for grads   */
+    float *norm1_w, *norm1_b, *qkv_w, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} vtBlockTensors;
+
+typedef struct {                          /* parameters OR their gradients (buffers NULL in grads)   */
+    float *pe_w, *pe_b;                   /* x_embedder.proj.{weight [D,C*pt*p*p], bias}             */
+    float *enc_patch_pe;                  /* encoder_patch_pe [Nv,D]           (buffer)              */
+    float *enc_query;                     /* encoder_latent_query_embed [Nq,D]                        */
+    float *dec_latent_pe;                 /* decoder_latent_pe [Nq,D]          (buffer)              */
+    float *dec_patch_query;               /* decoder_patch_query_embed [Nv,D]  (buffer)              */
+    float *dec_token_type;                /* decoder_patch_query_token_type_embed [D] or NULL         */
+    float *in_w, *in_b, *out_w, *out_b;   /* bottleneck.in_linear / out_linear                        */
+    float *codebook;                      /* bottleneck.regularizer.embedding.weight [K,d]            */
+    float *head_norm_w, *head_norm_b, *head_w, *head_b; /* final_layer.norm_final / linear          */
+    const vtBlockTensors* enc_blocks;     /* host array [depth_enc]                                   */
+    const vtBlockTensors* dec_blocks;     /* host array [depth_dec]                                   */
+} vtTokenizerTensors;
+
+typedef struct {                          /* forward outputs (device, caller-owned)                   */
+    float* pred_frames;                   /* [B,C,T,S,S]                                              */
+    float* encoded;                       /* [B,Nq,D]  'encoded'                                      */
+    int64_t* indices;                     /* [B,Nq]    'bottleneck_rep'                               */
+    float* projected_z;                   /* [B*Nq,d]  'projected_z' (in_linear output)               */
+    float* unregularized_z;               /* [B*Nq,d]                                                 */
+    float* regularized_z;                 /* [B*Nq,d]                                                 */
+    float* emb;                           /* [K,d]     'emb' (normalised codebook)                    */
+    float* losses;                        /* [4] loss_q, loss_commit, loss_codebook, mse              */
+    float* input_norms;                   /* [2] input_norm_first, input_norm_last                    */
+} vtTokenizerOutputs;
+
+typedef struct vtTokenizer vtTokenizer;
+
+int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** out);
+void vt_tokenizer_destroy(vtTokenizer* tk);
+size_t vt_tokenizer_workspace_bytes(const vtTokenizer* tk);
+int vt_tokenizer_init_workspace(vtTokenizer* tk, void* workspace, vtStream stream);
+/* fp32 master weights -> packed bf16 operands (call after every optimizer step) */
+int vt_tokenizer_pack(vtTokenizer* tk, const vtTokenizerTensors* params, void* workspace, vtStream stream);
+/* encode: video -> encoded + VQ outputs.  decode: encoded -> pred_frames.  forward = both. */
+int vt_tokenizer_encode(vtTokenizer* tk, const vtTokenizerTensors* params, const float* video, void* workspace,
+                        const vtTokenizerOutputs* out, uint64_t seed, vtStream stream);
+int vt_tokenizer_decode(vtTokenizer* tk, const vtTokenizerTensors* params, const float* encoded, void* workspace,
+                        float* pred_frames, vtStream stream);
+/* bottleneck.decode (models/bottleneck.py:166-168): indices -> encoded */
+int vt_tokenizer_codes_to_encoded(vtTokenizer* tk, const vtTokenizerTensors* params, const int64_t* indices, void* workspace,
+                                  float* encoded, vtStream stream);
+/* backward of forward(); stages run in order head(0), decoder blocks (1..depth_dec, last block
+ * first), bottleneck, encoder blocks, patch-embed; [stage_begin, stage_end) lets the caller
+ * interleave gradient all-reduce buckets between stages.  d_pred [B,C,T,S,S] fp32;
+ * gscal = device {dL/dloss_q, dL/dloss_commit, dL/dloss_codebook} or NULL. */
+int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* tk);
+int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
+                          void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
+                          vtStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VT_HIP_H */

@@ -1,0 +1,308 @@
+"""Op-level parity of every HIP kernel behind include/vt_hip.h against the CPU oracle / plain
+fp32 math on the same seeded inputs.  All calls go through the C ABI (ctypes).  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import inputs as gen
+from oracle import larp_oracle as O
+from oracle import vq_c
+from tests.golden.make_golden import vq_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import video_tokenizer_amd.hip as h
+    h.lib()
+    return h
+
+
+def bf(a):
+    return torch.from_numpy(a).to(torch.bfloat16)
+
+
+def _rand(shape, seed, std=1.0):
+    return gen.normal(shape, seed, std)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (256, 24, 768), (130, 1000, 192)])
+def test_gemm_nt_bf16_and_bias(hip, M, N, K):
+    A, B = bf(_rand((M, K), 1)), bf(_rand((N, K), 2))
+    bias = torch.from_numpy(_rand((N,), 3))
+    ref = A.float() @ B.float().t() + bias
+    out = hip.gemm_nt(A.cuda(), B.cuda(), hip.EPI_BF16, bias=bias.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.to(torch.bfloat16).float().numpy(), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_nt_exact_integers_asymmetric(hip):
+    """A = I (padded), asymmetric integer B: catches a transposed or permuted C write exactly."""
+    M, N, K = 128, 256, 128
+    A = torch.zeros(M, K)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    B = (torch.arange(N).reshape(N, 1) * 3 + torch.arange(K).reshape(1, K) % 7).float() % 64
+    ref = A @ B.t()
+    out = hip.gemm_nt(A.to(torch.bfloat16).cuda(), B.to(torch.bfloat16).cuda(), hip.EPI_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_nt_gelu_and_dgelu(hip):
+    M, N, K = 200, 320, 128
+    A, B = bf(_rand((M, K), 4, 0.5)), bf(_rand((N, K), 5, 0.5))
+    bias = torch.from_numpy(_rand((N,), 6, 0.1))
+    pre = (A.float() @ B.float().t() + bias).to(torch.bfloat16)
+    u, g = hip.gemm_nt(A.cuda(), B.cuda(), hip.EPI_BF16_GELU, bias=bias.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(u.float().cpu().numpy(), pre.float().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(g.float().cpu().numpy(), O.gelu_erf(u.float().cpu()).to(torch.bfloat16).float().numpy(), rtol=2e-2, atol=1e-2)
+    # dgelu: out = (A @ B^T) * gelu'(aux)
+    aux = bf(_rand((M, N), 7))
+    xr = aux.float().requires_grad_(True)
+    O.gelu_erf(xr).sum().backward()
+    ref = (A.float() @ B.float().t()) * xr.grad
+    out = hip.gemm_nt(A.cuda(), B.cuda(), hip.EPI_BF16_DGELU, aux=aux.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=3e-2)
+
+
+def test_gemm_nt_f32_residual_rowmod_rowmap(hip):
+    Bt, n, seq, off, N, K = 3, 40, 100, 60, 256, 128
+    M = Bt * n
+    A, B = bf(_rand((M, K), 8)), bf(_rand((N, K), 9))
+    bias = torch.from_numpy(_rand((N,), 10))
+    res = torch.from_numpy(_rand((Bt * seq, N), 11))
+    pe = torch.from_numpy(_rand((n, N), 12))
+    out = torch.full((Bt * seq, N), 7.0)
+    out_gpu, out2 = out.cuda(), torch.zeros(Bt * seq, N, dtype=torch.bfloat16).cuda()
+    hip.gemm_nt(A.cuda(), B.cuda(), hip.EPI_F32, bias=bias.cuda(), out=out_gpu, out2=out2, residual=res.cuda(),
+                rowmod=pe.cuda(), rowmod_period=n, omap=hip.RowMap(n, seq, off), round_bf16=True)
+    torch.cuda.synchronize()
+    core = (A.float() @ B.float().t() + bias).to(torch.bfloat16).float()
+    ref = out.clone()
+    for b in range(Bt):
+        rows = slice(b * seq + off, b * seq + off + n)
+        ref[rows] = core[b * n:(b + 1) * n] + res[rows] + pe
+    got = out_gpu.cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
+    assert torch.equal(got[:off], out[:off])  # untouched rows stay untouched
+    np.testing.assert_allclose(out2.float().cpu().numpy()[off:off + n], ref.to(torch.bfloat16).float().numpy()[off:off + n], rtol=1e-2, atol=3e-2)
+
+
+def test_gemm_tn_grouped(hip):
+    M = 256
+    dY1, X1 = bf(_rand((M, 192), 13)), bf(_rand((M, 136), 14))
+    dY2, X2 = bf(_rand((M, 64), 15)), bf(_rand((M, 320), 16))
+    out1 = torch.zeros(192, 136).cuda()
+    out2 = torch.full((40, 24), -5.0).cuda()
+    perm = torch.randperm(24, generator=torch.Generator().manual_seed(0)).to(torch.int32)
+    hip.gemm_tn_grouped([dict(A=dY1.cuda(), B=X1.cuda(), out=out1),
+                         dict(A=dY2.cuda(), B=X2.cuda(), out=out2, p_lim=24, q_lim=24, row_perm=perm.cuda())])
+    torch.cuda.synchronize()
+    ref1 = dY1.float().t() @ X1.float()
+    np.testing.assert_allclose(out1.cpu().numpy(), ref1.numpy(), rtol=1e-3, atol=1e-2)
+    ref2 = (dY2.float().t() @ X2.float())[:24, :24]
+    got2 = out2.cpu()
+    np.testing.assert_allclose(got2[perm.long()].numpy()[:, :24], ref2.numpy(), rtol=1e-3, atol=1e-2)
+    assert torch.all(got2[24:] == -5.0)
+
+
+def test_gemm_tn_exact_integers(hip):
+    M, P, Q = 128, 128, 128
+    dY = ((torch.arange(M).reshape(M, 1) * 5 + torch.arange(P).reshape(1, P) * 3) % 9).float()
+    X = ((torch.arange(M).reshape(M, 1) + torch.arange(Q).reshape(1, Q) * 7) % 5).float()
+    out = torch.zeros(P, Q).cuda()
+    hip.gemm_tn_grouped([dict(A=dY.to(torch.bfloat16).cuda(), B=X.to(torch.bfloat16).cuda(), out=out)])
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), dY.t() @ X)
+
+
+# ------------------------------------------------------------------------------------- row kernels
+def test_layernorm_fwd_bwd(hip):
+    rows, dim = 200, 768
+    x = torch.from_numpy(_rand((rows, dim), 20)) * 2 + 0.3
+    g = torch.from_numpy(gen.uniform((dim,), 21, 0.5, 1.5))
+    b = torch.from_numpy(_rand((dim,), 22, 0.1))
+    y, mean, rstd = hip.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), 1e-5)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (dim,), gr, br, 1e-5)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.detach().to(torch.bfloat16).float().numpy(), rtol=1e-2, atol=1e-2)
+    dy = bf(_rand((rows, dim), 23))
+    dres = torch.from_numpy(_rand((rows, dim), 24))
+    ref.backward(dy.float())
+    dx, dxb, dg, db, ds = hip.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, dres=dres.cuda())
+    torch.cuda.synchronize()
+    want = xr.grad + dres
+    np.testing.assert_allclose(dx.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dxb.float().cpu().numpy(), want.to(torch.bfloat16).float().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(ds.cpu().numpy(), want.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_layernorm_rowmap(hip):
+    Bt, seq, off, n, dim = 2, 50, 30, 20, 768
+    x = torch.from_numpy(_rand((Bt * seq, dim), 25))
+    g, b = torch.ones(dim), torch.zeros(dim)
+    y, mean, rstd = hip.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), 1e-6, rows=Bt * n, xmap=hip.RowMap(n, seq, off))
+    torch.cuda.synchronize()
+    sel = torch.cat([x[bb * seq + off: bb * seq + off + n] for bb in range(Bt)])
+    np.testing.assert_allclose(y.float().cpu().numpy(), F.layer_norm(sel, (dim,), eps=1e-6).to(torch.bfloat16).float().numpy(), rtol=1e-2, atol=1e-2)
+
+
+def test_colsum_batchsum_cast_assemble_pack(hip):
+    rows, width = 1000, 3072
+    s = bf(_rand((rows, width), 30))
+    np.testing.assert_allclose(hip.colsum(s.cuda()).cpu().numpy(), s.float().sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    f = torch.from_numpy(_rand((6 * 50, 768), 31))
+    m = hip.RowMap(20, 50, 30)
+    sel = torch.stack([f[bb * 50 + 30: bb * 50 + 50] for bb in range(6)])
+    np.testing.assert_allclose(hip.colsum(f.cuda(), rows=120, rmap=m).cpu().numpy(), sel.reshape(-1, 768).sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(hip.batch_sum(f.cuda(), 6, 20, rmap=m).cpu().numpy(), sel.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    c = hip.cast_rows(f.cuda(), rows=120, rmap=m)
+    assert torch.equal(c.cpu(), sel.reshape(-1, 768).to(torch.bfloat16))
+    dst = torch.zeros(6 * 50, 768).cuda()
+    src = torch.from_numpy(_rand((6 * 20, 768), 32))
+    tab = torch.from_numpy(_rand((20, 768), 33))
+    vec = torch.from_numpy(_rand((768,), 34))
+    hip.assemble_rows(dst, 50, 30, 6, 20, src=src.cuda(), table=tab.cuda(), vec=vec.cuda())
+    torch.cuda.synchronize()
+    want = torch.zeros(6, 50, 768)
+    want[:, 30:] = src.reshape(6, 20, 768) + tab + vec
+    np.testing.assert_allclose(dst.cpu().numpy(), want.reshape(-1, 768).numpy(), rtol=1e-6, atol=1e-6)
+    w = torch.from_numpy(_rand((100, 72), 35))
+    perm = torch.randperm(100, generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    wb, wt = hip.pack_weight(w.cuda(), row_perm=perm.cuda(), n_pad=128, k_pad=128)
+    torch.cuda.synchronize()
+    wp = w[perm.long()].to(torch.bfloat16)
+    assert torch.equal(wb.cpu()[:100, :72], wp) and torch.all(wb.cpu()[100:] == 0) and torch.all(wb.cpu()[:, 72:] == 0)
+    assert torch.equal(wt.cpu()[:72, :100], wp.t())
+
+
+@pytest.mark.parametrize("pt,p,T,S", [(2, 16, 4, 32), (4, 8, 4, 32), (2, 16, 16, 128)])
+def test_patchify_unpatchify(hip, pt, p, T, S):
+    B = 2
+    x = torch.from_numpy(gen.video_clips(B, T, S, 40))
+    rows = hip.patchify(x.cuda(), pt, p)
+    torch.cuda.synchronize()
+    ref = O.patchify(x, pt, p).reshape(-1, 3 * pt * p * p)
+    assert torch.equal(rows.cpu(), ref.to(torch.bfloat16))
+    # unpatchify takes (c,dt,dy,dx)-ordered rows; the reference head emits (dt,dy,dx,c): permute columns
+    kp = 3 * pt * p * p
+    y = torch.from_numpy(_rand((B * rows.shape[0] // B, kp), 41))
+    perm = torch.arange(kp).reshape(pt, p, p, 3).permute(3, 0, 1, 2).reshape(-1)  # packed col j <- reference col perm[j]
+    want = O.unpatchify(y.reshape(B, -1, kp), pt, p, S // p)
+    got = hip.unpatchify(y[:, perm].contiguous().cuda(), B, 3, T, S, pt, p)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+
+
+# -------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, L, H):
+    q, k, v = qkv.reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax((q @ k.transpose(-2, -1)) * 0.125, dim=-1)
+    return (att @ v).transpose(1, 2).reshape(B * L, H * 64)
+
+
+@pytest.mark.parametrize("B,L,H", [(1, 64, 1), (2, 192, 3), (1, 100, 2), (1, 333, 1)])
+def test_attention_fwd_bwd(hip, B, L, H):
+    qkv = bf(_rand((B * L, 3 * H * 64), 50 + L))
+    dO = bf(_rand((B * L, H * 64), 51 + L))
+    x = qkv.float().requires_grad_(True)
+    ref = _attn_ref(x, B, L, H)
+    ref.backward(dO.float())
+    o, lse2 = hip.attention_fwd(qkv.cuda(), B, L, H)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref.detach().numpy(), rtol=2e-2, atol=2e-2)
+    q, k, _ = qkv.float().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * 0.125, dim=-1) / np.log(2.0)
+    np.testing.assert_allclose(lse2.cpu().numpy(), lse_ref.numpy(), rtol=1e-3, atol=1e-2)
+    dqkv = hip.attention_bwd(qkv.cuda(), o, dO.cuda(), lse2, B, L, H)
+    torch.cuda.synchronize()
+    g = x.grad
+    err = (dqkv.float().cpu() - g).abs().max() / g.abs().max()
+    assert err < 3e-2, err
+
+
+def test_attention_integer_identity(hip):
+    """One-hot V columns + peaked scores: checks the transposed-read PV product element by element."""
+    B, L, H = 1, 64, 1
+    q = torch.zeros(L, 64)
+    k = torch.zeros(L, 64)
+    v = torch.zeros(L, 64)
+    for i in range(L):
+        q[i, i % 64] = 16.0
+        k[i, i % 64] = 16.0           # score(i,i) = 256*0.125 = 32 >> others (0)
+        v[i, (i * 7 + 3) % 64] = float(i % 13 + 1)
+    qkv = torch.stack([q, k, v], dim=1).reshape(L, 3 * 64).to(torch.bfloat16)
+    o, _ = hip.attention_fwd(qkv.cuda(), B, L, H)
+    torch.cuda.synchronize()
+    ref = _attn_ref(qkv.float(), B, L, H)
+    np.testing.assert_allclose(o.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
+# --------------------------------------------------------------------------------------------- VQ
+@pytest.mark.parametrize("case", vq_cases())
+@pytest.mark.parametrize("mode", ["L", "D"])
+def test_vq_forward_bit_exact_vs_c_oracle(hip, case, mode, golden_dir):
+    (b, n), K, d, seed = case
+    W = gen.kaiming_uniform_codebook(K, d, seed)
+    z = gen.normal((b * n, d), seed + 1000)
+    inv_tau = float(np.float32(1.0 / 0.03))
+    ref = vq_c.vq_forward(z, W, mode)
+    o = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 0 if mode == "L" else 1, inv_tau=inv_tau, ldp=64)
+    torch.cuda.synchronize()
+    assert np.array_equal(o["zn"].cpu().numpy(), ref["z"])            # normalisation bit-exact
+    assert np.array_equal(o["E"].cpu().numpy(), ref["emb"])
+    assert np.array_equal(o["idx"].cpu().numpy(), ref["idx"])          # indices bit-exact
+    assert np.array_equal(o["rz"].cpu().numpy(), ref["regularized_z"])
+    np.testing.assert_allclose(o["losses"].cpu().numpy()[:3], [ref["loss_q"], ref["loss_commit"], ref["loss_codebook"]], rtol=1e-5)
+    assert torch.equal(o["rz_pad"].cpu()[:, :d], torch.from_numpy(ref["regularized_z"]).to(torch.bfloat16))
+    assert torch.all(o["rz_pad"].cpu()[:, d:] == 0)
+    # and against the reference's own indices (golden fixture)
+    f = np.load(f"{golden_dir}/vq_N{b * n}_K{K}_d{d}_{mode}.npz")
+    assert np.array_equal(o["idx"].cpu().numpy(), f["idx"].reshape(-1).astype(np.int64))
+
+
+@pytest.mark.parametrize("case", vq_cases()[:2])
+def test_vq_backward_matches_reference_grads(hip, case, golden_dir):
+    (b, n), K, d, seed = case
+    f = np.load(f"{golden_dir}/vq_N{b * n}_K{K}_d{d}_L.npz")
+    W = gen.kaiming_uniform_codebook(K, d, seed)
+    z = gen.normal((b * n, d), seed + 1000)
+    g = gen.normal((b * n, d), seed + 2000)
+    o = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 0)
+    gscal = torch.tensor([0.7, 0.0, 0.0]).cuda()
+    dz, _, dW = hip.vq_backward(torch.from_numpy(g).cuda(), gscal, o)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dz.cpu().numpy(), f["dz"].reshape(-1, d), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dW.cpu().numpy(), f["dE"], rtol=1e-4, atol=1e-6)
+
+
+def test_vq_stochastic_mode_matches_softmax_distribution(hip):
+    """mode 2 has no bit-exact oracle (torch.multinomial CPU != GPU): chi-square of the sampled index
+    frequencies of ONE token replicated N times against softmax(cos/tau) from the oracle."""
+    K, d, N = 256, 24, 65536
+    W = gen.kaiming_uniform_codebook(K, d, 77)
+    z1 = gen.normal((1, d), 78)
+    z = np.repeat(z1, N, axis=0)
+    o = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 2, inv_tau=1.0 / 0.3, seed=1234)
+    torch.cuda.synchronize()
+    zn = F.normalize(torch.from_numpy(z1), dim=-1)
+    en = F.normalize(torch.from_numpy(W), dim=-1)
+    probs = torch.softmax((zn @ en.t()) / 0.3, dim=-1).double().numpy().reshape(-1)
+    cnt = np.bincount(o["idx"].cpu().numpy(), minlength=K).astype(np.float64)
+    keep = probs * N >= 5
+    chi2 = (((cnt - probs * N) ** 2) / (probs * N))[keep].sum()
+    dof = keep.sum() - 1
+    assert chi2 < dof + 6 * np.sqrt(2 * dof), (chi2, dof)
+    # a different seed gives a different draw
+    o2 = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 2, inv_tau=1.0 / 0.3, seed=99)
+    assert (o2["idx"] != o["idx"]).float().mean() > 0.5

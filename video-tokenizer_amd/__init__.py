@@ -1,0 +1,8 @@
+"""MI355X-native LARP tokenizer hot path (encode -> quantize -> decode training step).
+
+Host-side mirror of the reference's model-registry interface over the C ABI of libvt_hip.so
+(include/vt_hip.h).  There is no CPU fallback: every compute entry point raises if the HIP
+library is missing or the tensors are not on a GPU.
+"""
+from . import hip  # noqa: F401  (ctypes binding; loading is lazy)
+from .registry import make, models, register  # noqa: F401

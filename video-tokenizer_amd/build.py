@@ -1,0 +1,55 @@
+"""Build libvt_hip.so (all gfx950 kernels + the C ABI of include/vt_hip.h) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU; the built .so is git-ignored but travels to the
+GPU box with the snapshot.  Usage: python video-tokenizer_amd/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvt_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["vt_api.cpp", "vt_gemm.hip", "vt_norm.hip", "vt_patch.hip", "vt_vq.hip", "vt_attention.hip", "vt_engine.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    deps = [os.path.join(CSRC, "vt_common.h"), os.path.join(HERE, "..", "include", "vt_hip.h")]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        op = os.path.join(HERE, "_obj", os.path.splitext(src)[0] + ".o")
+        objs.append(op)
+        if force or _newer(sp, op) or any(_newer(d, op) for d in deps):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {src} failed ---\n{out.decode()}\n")
+        elif verbose and out:
+            sys.stderr.write(out.decode())
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,22 @@
+// C-ABI plumbing shared by every entry point of libvt_hip.so: version and thread-local error text.
+#include <stdarg.h>
+
+#include "vt_common.h"
+
+static thread_local char g_err[512] = "";
+
+void vt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int vt_abi_version(void) { return 1; }
+
+extern "C" int vt_last_error(char* buf, size_t n) {
+    if (!buf || n == 0) return VT_ERR_INVALID;
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+    return VT_OK;
+}

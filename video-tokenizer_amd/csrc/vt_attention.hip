@@ -1,0 +1,401 @@
+// Fused multi-head attention (no mask, head_dim 64) for gfx950: forward with online softmax and the
+// two recompute backward kernels.  Replaces timm Attention's F.scaled_dot_product_attention inside
+// timm Block (constructed at /root/reference/models/transformer.py:52-59) and its autograd.
+//
+// Layouts: qkv bf16 [B, L, 3, H, 64] (the qkv Linear's output, reshape (B,N,3,H,hd)); o / dO bf16
+// [B, L, H, 64]; lse2 fp32 [B, H, L] = log2-domain log-sum-exp of the scaled scores; delta fp32 [B,H,L].
+//
+// Common skeleton (one workgroup = 4 waves, each wave owns 32 "stationary" rows held in registers as
+// MFMA B operands; 64-row "streaming" tiles are staged global -> LDS with 16-B global_load_lds,
+// double-buffered, one barrier per tile):
+//   score-like products  X[stream_row][own_row] = Tile . Own^T      : A = tile rows by ds_read_b128
+//   accumulate products  Acc^T[d][own_row]    += Tile^T . X         : A = tile columns by
+//                        ds_read_b64_tr_b16; B = the fp32 accumulator X converted to bf16 IN REGISTERS
+//                        (a 32x32 accumulator has its column on the lane and its rows in the 16
+//                        registers, so registers 8s..8s+7 are the B fragment of k-step s; the k order
+//                        inside a step is row 16s + 8(j>>2) + 4*half + (j&3), which the transposed read
+//                        of the other operand follows).
+// Because the own row (query in fwd/dQ, key in dK/dV) sits on the lane, softmax statistics are
+// lane-local: no cross-lane reduction except one exchange between the two lane halves.
+//
+// LDS tile image: [64 rows][64 bf16] = 128-B rows of eight 16-B chunks, physical chunk =
+// logical ^ f(row), f(row) = (((row>>1)&1)<<2) | ((row>>2)&3): conflict-free for BOTH the b128 row
+// reads of a 32x32x16 A operand and the transposed b64 reads (derivation in DESIGN.md).  The image is
+// written lane-linearly by the LDS-DMA, so the XOR goes on the per-lane source address.
+#include "vt_common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int TILE = 64 * 128;  // bytes per [64][64] bf16 tile
+
+__device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, char* lds, int tid, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = i * 256 + tid;
+        const int row = slot >> 3;
+        const int lc = (slot & 7) ^ fsw(row);
+        int gr = row0 + row;
+        gr = gr < L ? gr : L - 1;
+        glds16(src + (int64_t)gr * rs + lc * 8, lds + (i * 256 + wave * 64) * 16);
+    }
+}
+
+// A operand of a 32x32x16 MFMA from tile rows r0..r0+31, k-step s (16 columns)
+__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int r0, int s, int lane) {
+    const int row = r0 + (lane & 31);
+    const int lc = 2 * s + (lane >> 5);
+    return *(const bf16x8*)(lds + row * 128 + ((lc ^ fsw(row)) << 4));
+}
+
+// A operand [i = column c0 + (lane&31)][k = tile rows], k order matched to an accumulator used as B:
+// element j  <->  tile row rbase + 16*sp + 8*(j>>2) + 4*(lane>>5) + (j&3)
+__device__ __forceinline__ bf16x8 trfrag(const char* lds, int rbase, int sp, int c0, int lane) {
+    const int g = lane >> 4, lam = lane & 15;
+    const int r0 = rbase + 16 * sp + 4 * (g >> 1) + (lam >> 2);
+    const int r1 = r0 + 8;
+    const int cb = c0 + 16 * (g & 1);
+    const int lc = (cb >> 3) + ((lam & 3) >> 1);
+    const int bo = (lam & 1) << 3;
+    const bf16x4 lo = lds_read_tr16(lds + r0 * 128 + ((lc ^ fsw(r0)) << 4) + bo);
+    const bf16x4 hi = lds_read_tr16(lds + r1 * 128 + ((lc ^ fsw(r1)) << 4) + bo);
+    return cat4(lo, hi);
+}
+
+// own 32 rows as B-operand fragments straight from global: f[s] = X[row0 + (lane&31)][16s + 8*(lane>>5) ..+7]
+__device__ __forceinline__ void load_own(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, int lane, bf16x8 (&f)[4]) {
+    int r = row0 + (lane & 31);
+    r = r < L ? r : L - 1;
+    const bf16_t* p = src + (int64_t)r * rs + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = *(const bf16x8*)(p + 16 * s);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int sp) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f2bf(a[8 * sp + j]);
+    return r;
+}
+
+__device__ __forceinline__ int reg_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// store acc^T[d][own_row] tiles (2 x f32x16) as bf16 into dst[own_row][d], 8 B per store
+__device__ __forceinline__ void store_own(const f32x16 (&acc)[2], float mul, bf16_t* __restrict__ dst, int64_t rs, int row, bool ok, int half) {
+    if (!ok) return;
+    bf16_t* p = dst + (int64_t)row * rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[dt][4 * g4 + e] * mul);
+            *(bf16x4*)(p + dt * 32 + 8 * g4 + 4 * half) = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
+                                                           int L, int H, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int64_t rs = (int64_t)3 * H * HD;
+    const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
+    const bf16_t* kb = qb + (int64_t)H * HD;
+    const bf16_t* vb = kb + (int64_t)H * HD;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    bf16x8 qf[4];
+    load_own(qb, rs, q0, L, lane, qf);
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+    float m = -__builtin_inff(), lsum = 0.f;
+
+    const int nt = (L + 63) / 64;
+    // LDS: [buffer 0: K | V][buffer 1: K | V]
+    stage64(kb, rs, 0, L, smem, tid, wave);
+    stage64(vb, rs, 0, L, smem + TILE, tid, wave);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            stage64(kb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE, tid, wave);
+            stage64(vb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+        }
+        const char* kl = smem + cur * 2 * TILE;
+        const char* vl = kl + TILE;
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc[kt], 0, 0, 0);
+        }
+        const bool tail = (t == nt - 1) && (L & 63);
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = sacc[kt][r] * scale_log2e;
+                if (tail && (t * 64 + kt * 32 + reg_row(r, half) >= L)) x = -__builtin_inff();
+                sacc[kt][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sacc[kt][r] - mn);
+                sacc[kt][r] = p;
+                ps += p;
+            }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(sacc[kt], sp);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(vl, kt * 32, sp, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32);
+    const int q = q0 + (lane & 31);
+    const bool ok = q < L;
+    store_own(oacc, 1.0f / ltot, o + (int64_t)b * L * H * HD + (int64_t)h * HD, (int64_t)H * HD, q, ok, half);
+    if (ok && half == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);  // v_log_f32 = log2
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// ------------------------------------------------------------------------------------------------
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO, float* __restrict__ delta, int64_t BL, int L, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over BL * H
+    if (idx >= BL * H) return;
+    const int h = idx % H;
+    const int64_t bl = idx / H;
+    const bf16_t* po = o + idx * HD;
+    const bf16_t* pd = dO + idx * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 a = *(const bf16x8*)(po + c * 8), d = *(const bf16x8*)(pd + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(d[j]);
+    }
+    const int64_t b = bl / L, q = bl % L;
+    delta[(b * H + h) * L + q] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: own rows = queries; streams K (row reads + transposed reads) and V (row reads)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                              const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int64_t rs = (int64_t)3 * H * HD, ors = (int64_t)H * HD;
+    const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
+    const bf16_t* kb = qb + (int64_t)H * HD;
+    const bf16_t* vb = kb + (int64_t)H * HD;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q = q0 + (lane & 31);
+    const int qc = q < L ? q : L - 1;
+
+    bf16x8 qf[4], dof[4];
+    load_own(qb, rs, q0, L, lane, qf);
+    load_own(dO + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, dof);
+    const float my_lse = lse2[((int64_t)b * H + h) * L + qc];
+    const float my_delta = delta[((int64_t)b * H + h) * L + qc];
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[0][r] = dq[1][r] = 0.f;
+
+    const int nt = (L + 63) / 64;
+    // LDS: [buffer 0: K | V][buffer 1: K | V]
+    stage64(kb, rs, 0, L, smem, tid, wave);
+    stage64(vb, rs, 0, L, smem + TILE, tid, wave);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            stage64(kb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE, tid, wave);
+            stage64(vb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+        }
+        const bool tail = (t == nt - 1) && (L & 63);
+        const char* kl = smem + cur * 2 * TILE;
+        const char* vl = kl + TILE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sacc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(vl, kt * 32, s, lane), dof[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(sacc[r] * scale_log2e - my_lse);
+                if (tail && (t * 64 + kt * 32 + reg_row(r, half) >= L)) p = 0.f;
+                sacc[r] = p * (dp[r] - my_delta);  // dS (unscaled)
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 dsf = pack8(sacc, sp);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(kl, kt * 32, sp, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    store_own(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: own rows = keys; streams Q and dO tiles (both row reads and transposed reads) + lse2/delta
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                               const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int64_t rs = (int64_t)3 * H * HD, ors = (int64_t)H * HD;
+    const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
+    const bf16_t* kb = qb + (int64_t)H * HD;
+    const bf16_t* vb = kb + (int64_t)H * HD;
+    const bf16_t* dob = dO + (int64_t)b * L * ors + (int64_t)h * HD;
+    const float* lse_b = lse2 + ((int64_t)b * H + h) * L;
+    const float* del_b = delta + ((int64_t)b * H + h) * L;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int key = k0 + (lane & 31);
+
+    bf16x8 kf[4], vf[4];
+    load_own(kb, rs, k0, L, lane, kf);
+    load_own(vb, rs, k0, L, lane, vf);
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f;
+
+    // LDS: per buffer  Q tile | dO tile | lse2[64] | delta[64]
+    constexpr int BUF = 2 * TILE + 512;
+    const int nt = (L + 63) / 64;
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * BUF;
+        stage64(qb, rs, t * 64, L, base, tid, wave);
+        stage64(dob, ors, t * 64, L, base + TILE, tid, wave);
+        if (wave < 2) {  // wave 0: lse2[64], wave 1: delta[64] by 4-byte LDS-DMA (rows past L clamped; masked at use)
+            int qq = t * 64 + lane;
+            qq = qq < L ? qq : L - 1;
+            glds4((wave == 0 ? lse_b : del_b) + qq, base + 2 * TILE + wave * 256);
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        const bool tail = (t == nt - 1) && (L & 63);
+        const char* qt_l = smem + cur * BUF;
+        const char* do_l = qt_l + TILE;
+        const float* lse_l = (const float*)(qt_l + 2 * TILE);
+        const float* del_l = lse_l + 64;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 sacc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_l, qt * 32, s, lane), kf[s], sacc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qr = qt * 32 + reg_row(r, half);
+                float p = __builtin_amdgcn_exp2f(sacc[r] * scale_log2e - lse_l[qr]);
+                if (tail && (t * 64 + qr >= L)) p = 0.f;
+                sacc[r] = p;
+                dp[r] = p * (dp[r] - del_l[qr]);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack8(sacc, sp);
+                const bf16x8 dsf = pack8(dp, sp);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(do_l, qt * 32, sp, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_l, qt * 32, sp, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    bf16_t* dkb = dqkv + (int64_t)b * L * rs + (int64_t)h * HD + (int64_t)H * HD;
+    store_own(dk, scale, dkb, rs, key, key < L, half);
+    store_own(dv, 1.0f, dkb + (int64_t)H * HD, rs, key, key < L, half);
+}
+
+}  // namespace
+
+extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream) {
+    VT_CHECK_ARG(qkv && o && lse2, "vt_attention_fwd: null pointer");
+    VT_CHECK_ARG(hd == 64, "vt_attention_fwd: head_dim %d unsupported (64 only)", hd);
+    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_fwd: bad shape");
+    const float sl2 = 0.125f * 1.44269504088896340736f;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((L + 127) / 128, B * H), dim3(256), 4 * TILE, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, sl2);
+    VT_CHECK_LAUNCH("vt_attention_fwd");
+    return VT_OK;
+}
+
+extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
+                                int32_t hd, void* dqkv, float* delta_ws, vtStream stream) {
+    VT_CHECK_ARG(qkv && o && dO && lse2 && dqkv && delta_ws, "vt_attention_bwd: null pointer");
+    VT_CHECK_ARG(hd == 64, "vt_attention_bwd: head_dim %d unsupported (64 only)", hd);
+    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const float scale = 0.125f, sl2 = 0.125f * 1.44269504088896340736f;
+    const int64_t BL = (int64_t)B * L;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((BL * H + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o, (const bf16_t*)dO, delta_ws, BL, L, H);
+    const dim3 grid((L + 127) / 128, B * H);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * TILE, s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, scale, sl2);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * (2 * TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, scale, sl2);
+    VT_CHECK_LAUNCH("vt_attention_bwd");
+    return VT_OK;
+}

@@ -1,0 +1,96 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the LARP tokenizer path.
+// Wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vt_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define VT_LDS __attribute__((address_space(3)))
+#define VT_GLB __attribute__((address_space(1)))
+
+// ---- error plumbing (thread-local message, negative codes across the C ABI) ----
+void vt_set_error(const char* fmt, ...);
+#define VT_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            vt_set_error(__VA_ARGS__);          \
+            return VT_ERR_INVALID;              \
+        }                                       \
+    } while (0)
+#define VT_CHECK_LAUNCH(name)                                              \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            vt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return VT_ERR_LAUNCH;                                          \
+        }                                                                  \
+    } while (0)
+
+// ---- device helpers ----
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// 16-byte async global -> LDS copy: LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const VT_GLB void*)gsrc, (VT_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const VT_GLB void*)gsrc, (VT_LDS void*)lds_wave_base, 4, 0, 0);
+}
+
+// transposed LDS read: per 16-lane group a 4-row x 16-col block of 16-bit elements; lane i of the
+// group receives column i (4 rows).  addr = this lane's 8-byte piece (row q = (i>>2), cols 4*(i&3)..).
+__device__ __forceinline__ bf16x4 lds_read_tr16(const void* lds_addr) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VT_LDS s16x4*)lds_addr);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+__device__ __forceinline__ float round_bf16(float x) { return (float)((bf16_t)x); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// bijective XCD-aware remap (8 XCDs, blocks dealt round-robin): gives each XCD one contiguous chunk
+// of the tile list so neighbouring tiles share operand panels through that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// output row map: r -> (r / grp) * stride + off + (r % grp); grp == 0 means identity
+struct RowMap {
+    int grp;
+    int64_t stride, off;
+    __host__ __device__ __forceinline__ int64_t operator()(int64_t r) const {
+        return grp ? (r / grp) * stride + off + (r % grp) : r;
+    }
+};
+#endif

@@ -1,0 +1,364 @@
+// bf16 MFMA GEMMs for gfx950.
+//
+//  gemm_nt_kernel : C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)  + fused epilogues
+//  gemm_tn_kernel : C[P,Q] = A[M,P]^T . B[M,Q]   (contraction over the ROW index of both operands:
+//                   fragments come from LDS through the transposed read ds_read_b64_tr_b16)
+//
+// Structure of both: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
+// 4x4 accumulators of v_mfma_f32_16x16x32_bf16), BK = 64, operands staged global -> LDS with
+// 16-byte global_load_lds into a lane-linear image; the XOR swizzle that makes the fragment reads
+// bank-conflict-free is applied to the per-lane SOURCE address and to the read address (never to the
+// LDS destination).  Two LDS buffers: the loads of K-tile t+1 are in flight while tile t is
+// multiplied; one barrier per K-tile.  64 KiB LDS => 2 workgroups per CU.
+//
+// The MFMA is issued as D' = B_frag x A_frag so that one lane ends up with FOUR CONSECUTIVE OUTPUT
+// COLUMNS of one output row (16 B of fp32 / 8 B of bf16 per store) instead of four rows.
+#include "vt_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_B = BM * BK * 2;  // 16 KiB per operand tile
+
+// ------------------------------------------------------------------------------------------------
+// NT
+// ------------------------------------------------------------------------------------------------
+struct NTArgs {
+    vtGemmNT p;
+    int tiles_m, tiles_n;
+};
+
+// [128 rows][64 k] bf16 tile, 128-B rows, 16-B chunks; physical chunk = logical ^ ((row>>1)&7)
+__device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0,
+                                         char* lds, int tid, int wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int slot = i * 256 + tid;
+        const int row = slot >> 3;
+        const int lc = (slot & 7) ^ ((row >> 1) & 7);
+        int gr = row0 + row;
+        gr = gr < nrows ? gr : nrows - 1;
+        glds16(g + (int64_t)gr * ld + k0 + lc * 8, lds + (i * 256 + wave * 64) * 16);
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag_nt(const char* lds, int row, int lchunk) {
+    return *(const bf16x8*)(lds + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const vtGemmNT& p = a.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int sid = xcd_remap(blockIdx.x, nwg);
+    const int tm = sid / a.tiles_n, tn = sid % a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* B = (const bf16_t*)p.B;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.K / BK;
+    // LDS: [buffer 0: A | B][buffer 1: A | B]
+
+    stage_nt(A, p.lda, m0, p.M, 0, smem, tid, wave);
+    stage_nt(B, p.ldb, n0, p.N, 0, smem + TILE_B, tid, wave);
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            stage_nt(A, p.lda, m0, p.M, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_B, tid, wave);
+            stage_nt(B, p.ldb, n0, p.N, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_B + TILE_B, tid, wave);
+        }
+        const char* la = smem + cur * 2 * TILE_B;
+        const char* lb = la + TILE_B;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_nt(la, wr * 64 + i * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfv[j] = frag_nt(lb, wc * 64 + j * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][r] = C[m0 + wr*64 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
+    const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+        const int64_t orow = (EPI == VT_EPI_F32) ? omap(m) : (int64_t)m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            const bool full = (n + 3 < p.N);
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) v[r] += p.bias[n + r];
+            }
+            if constexpr (EPI == VT_EPI_BF16) {
+                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + n;
+                if (full) {
+                    *(bf16x4*)o = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = f2bf(v[r]);
+                }
+            } else if constexpr (EPI == VT_EPI_BF16_GELU) {
+                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + n;
+                bf16_t* o2 = (bf16_t*)p.out2 + orow * p.ldo2 + n;
+                bf16_t u[4], gl[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u[r] = f2bf(v[r]);
+                    gl[r] = f2bf(gelu_erf(bf2f(u[r])));  // GELU of the bf16-rounded pre-activation (autocast order)
+                }
+                if (full) {
+                    *(bf16x4*)o = (bf16x4){u[0], u[1], u[2], u[3]};
+                    *(bf16x4*)o2 = (bf16x4){gl[0], gl[1], gl[2], gl[3]};
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) { o[r] = u[r]; o2[r] = gl[r]; }
+                }
+            } else if constexpr (EPI == VT_EPI_BF16_DGELU) {
+                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + n;
+                const bf16_t* ux = (const bf16_t*)p.aux + (int64_t)m * p.ldaux + n;
+                if (full) {
+                    const bf16x4 uu = *(const bf16x4*)ux;
+                    *(bf16x4*)o = (bf16x4){f2bf(v[0] * gelu_erf_grad(bf2f(uu[0]))), f2bf(v[1] * gelu_erf_grad(bf2f(uu[1]))),
+                                           f2bf(v[2] * gelu_erf_grad(bf2f(uu[2]))), f2bf(v[3] * gelu_erf_grad(bf2f(uu[3])))};
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = f2bf(v[r] * gelu_erf_grad(bf2f(ux[r])));
+                }
+            } else {  // VT_EPI_F32
+                if (p.round_bf16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = round_bf16(v[r]);
+                }
+                float* o = (float*)p.out + orow * p.ldo + n;
+                if (p.residual) {
+                    const float* rs = p.residual + orow * p.ldr + n;
+                    if (full) {
+                        const f32x4 rv = *(const f32x4*)rs;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += rs[r];
+                    }
+                }
+                if (p.rowmod) {
+                    const float* rm = p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n;
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += rm[r];
+                }
+                if (full) {
+                    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
+                }
+                if (p.out2) {
+                    bf16_t* o2 = (bf16_t*)p.out2 + orow * p.ldo2 + n;
+                    if (full) {
+                        *(bf16x4*)o2 = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.N; ++r) o2[r] = f2bf(v[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN (grouped)
+// ------------------------------------------------------------------------------------------------
+struct TNArgs {
+    vtGemmTN p[VT_TN_MAX_GROUP];
+    int tile_start[VT_TN_MAX_GROUP + 1];
+    int n;
+};
+
+// [64 m-rows][128 cols] bf16 tile, 256-B rows, 16 chunks; physical chunk = logical ^ fT(row)
+__device__ __forceinline__ int swz_tn(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+
+__device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ g, int64_t ld, int m0, int c0, int ncols,
+                                         char* lds, int tid, int wave) {
+    const int maxchunk = (ncols >> 3) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int slot = i * 256 + tid;
+        const int row = slot >> 4;
+        const int lc = (slot & 15) ^ swz_tn(row);
+        int gc = (c0 >> 3) + lc;
+        gc = gc < maxchunk ? gc : maxchunk;  // columns past the matrix edge: any in-bounds data (never stored)
+        glds16(g + (int64_t)(m0 + row) * ld + gc * 8, lds + (i * 256 + wave * 64) * 16);
+    }
+}
+
+// fragment for the 16 columns starting at `col` (multiple of 16), k-step base kb (0/32): lane (g = l>>4,
+// i = l&15) gets tile[kb + 8g + 0..7][col + i]
+__device__ __forceinline__ bf16x8 frag_tn(const char* lds, int col, int kb, int lane) {
+    const int g = lane >> 4, lam = lane & 15;
+    const int q = lam >> 2, pp = lam & 3;
+    const int lchunk = (col >> 3) + (pp >> 1);
+    const int r0 = kb + 8 * g + q, r1 = r0 + 4;
+    const bf16x4 lo = lds_read_tr16(lds + r0 * 256 + ((lchunk ^ swz_tn(r0)) << 4) + ((pp & 1) << 3));
+    const bf16x4 hi = lds_read_tr16(lds + r1 * 256 + ((lchunk ^ swz_tn(r1)) << 4) + ((pp & 1) << 3));
+    return cat4(lo, hi);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = a.tile_start[a.n];
+    const int sid = xcd_remap(blockIdx.x, nwg);
+    int g = 0;
+    while (g + 1 < a.n && sid >= a.tile_start[g + 1]) ++g;
+    const vtGemmTN& p = a.p[g];
+    const int local = sid - a.tile_start[g];
+    const int tiles_q = (p.q_lim + BN - 1) / BN;
+    const int p0 = (local / tiles_q) * BM, q0 = (local % tiles_q) * BN;
+
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* B = (const bf16_t*)p.B;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.M / BK;
+    // LDS: [buffer 0: A | B][buffer 1: A | B]
+
+    stage_tn(A, p.lda, 0, p0, p.P, smem, tid, wave);
+    stage_tn(B, p.ldb, 0, q0, p.Q, smem + TILE_B, tid, wave);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            stage_tn(A, p.lda, (t + 1) * BK, p0, p.P, smem + (cur ^ 1) * 2 * TILE_B, tid, wave);
+            stage_tn(B, p.ldb, (t + 1) * BK, q0, p.Q, smem + (cur ^ 1) * 2 * TILE_B + TILE_B, tid, wave);
+        }
+        const char* la = smem + cur * 2 * TILE_B;
+        const char* lb = la + TILE_B;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_tn(la, wr * 64 + i * 16, kk * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfv[j] = frag_tn(lb, wc * 64 + j * 16, kk * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // acc[i][j][r] = C[p0 + wr*64 + i*16 + (lane&15)][q0 + wc*64 + j*16 + (lane>>4)*4 + r]
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pr = p0 + wr * 64 + i * 16 + fr;
+        if (pr >= p.p_lim) continue;
+        const int64_t orow = p.row_perm ? (int64_t)p.row_perm[pr] : (int64_t)pr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qc = q0 + wc * 64 + j * 16 + fq * 4;
+            if (qc >= p.q_lim) continue;
+            float* o = p.out + orow * p.ldo + qc;
+            if (qc + 3 < p.q_lim && ((p.ldo & 3) == 0)) {
+                *(f32x4*)o = acc[i][j];
+            } else {
+                for (int r = 0; r < 4 && qc + r < p.q_lim; ++r) o[r] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
+    const vtGemmNT& p = *ph;
+    VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
+    VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
+    VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
+    VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
+    VT_CHECK_ARG(p.ldo % 4 == 0, "vt_gemm_nt: ldo must be a multiple of 4");
+    if (p.epi == VT_EPI_BF16_GELU) VT_CHECK_ARG(p.out2 && p.ldo2 % 4 == 0, "vt_gemm_nt: GELU epilogue needs out2");
+    if (p.epi == VT_EPI_BF16_DGELU) VT_CHECK_ARG(p.aux && p.ldaux % 4 == 0, "vt_gemm_nt: DGELU epilogue needs aux");
+    if (p.epi == VT_EPI_F32) {
+        VT_CHECK_ARG(!p.residual || p.ldr % 4 == 0, "vt_gemm_nt: ldr must be a multiple of 4");
+        VT_CHECK_ARG(!p.rowmod || p.rowmod_period > 0, "vt_gemm_nt: rowmod needs a period");
+        VT_CHECK_ARG(!p.out2 || p.ldo2 % 4 == 0, "vt_gemm_nt: ldo2 must be a multiple of 4");
+    } else {
+        VT_CHECK_ARG(p.omap.grp == 0, "vt_gemm_nt: output row map only with VT_EPI_F32");
+    }
+    NTArgs a;
+    a.p = p;
+    a.tiles_m = (p.M + BM - 1) / BM;
+    a.tiles_n = (p.N + BN - 1) / BN;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    const size_t lds = 4 * TILE_B;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p.epi) {
+        case VT_EPI_BF16: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_BF16>, grid, block, lds, s, a); break;
+        case VT_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_BF16_GELU>, grid, block, lds, s, a); break;
+        case VT_EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_F32>, grid, block, lds, s, a); break;
+        case VT_EPI_BF16_DGELU: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_BF16_DGELU>, grid, block, lds, s, a); break;
+        default: vt_set_error("vt_gemm_nt: unknown epilogue %d", p.epi); return VT_ERR_INVALID;
+    }
+    VT_CHECK_LAUNCH("vt_gemm_nt");
+    return VT_OK;
+}
+
+extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream) {
+    VT_CHECK_ARG(ph && n > 0 && n <= VT_TN_MAX_GROUP, "vt_gemm_tn_grouped: 1..%d problems", VT_TN_MAX_GROUP);
+    TNArgs a;
+    a.n = n;
+    a.tile_start[0] = 0;
+    for (int g = 0; g < n; ++g) {
+        const vtGemmTN& p = ph[g];
+        VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_tn_grouped[%d]: null operand", g);
+        VT_CHECK_ARG(p.M > 0 && p.M % BK == 0, "vt_gemm_tn_grouped[%d]: M=%d must be a multiple of 64 (pad rows with zeros)", g, p.M);
+        VT_CHECK_ARG(p.P >= 8 && p.Q >= 8 && p.P % 8 == 0 && p.Q % 8 == 0, "vt_gemm_tn_grouped[%d]: P=%d Q=%d must be multiples of 8", g, p.P, p.Q);
+        VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.P && p.ldb >= p.Q, "vt_gemm_tn_grouped[%d]: bad lda/ldb", g);
+        VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_tn_grouped[%d]: A/B must be 16-byte aligned", g);
+        VT_CHECK_ARG(p.p_lim > 0 && p.p_lim <= p.P && p.q_lim > 0 && p.q_lim <= p.Q, "vt_gemm_tn_grouped[%d]: bad limits", g);
+        a.p[g] = p;
+        const int tp = (p.p_lim + BM - 1) / BM, tq = (p.q_lim + BN - 1) / BN;
+        a.tile_start[g + 1] = a.tile_start[g] + tp * tq;
+    }
+    const dim3 grid(a.tile_start[n]), block(256);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 4 * TILE_B, (hipStream_t)stream, a);
+    VT_CHECK_LAUNCH("vt_gemm_tn_grouped");
+    return VT_OK;
+}

@@ -1,0 +1,351 @@
+// HBM-bound row kernels for gfx950: LayerNorm forward/backward (fp32 statistics, bf16 output for the
+// following MFMA GEMM), column sums (bias gradients), batch sums (query-embedding gradients), weight
+// packing (fp32 master -> bf16 [N,K] and its transpose [K,N]), fp32->bf16 row casts and sequence
+// assembly.  One wave (64 lanes) owns one row; each lane moves 16 B per access.
+#include "vt_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * gamma + beta, y in bf16, stats saved in fp32
+// ------------------------------------------------------------------------------------------------
+template <int V>  // dim = 256 * V
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, int64_t rows,
+                                                      bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int DIM = 256 * V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 g[V], b[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        g[i] = *(const f32x4*)(gamma + (i * 64 + lane) * 4);
+        b[i] = *(const f32x4*)(beta + (i * 64 + lane) * 4);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + xmap(row) * DIM;
+        f32x4 v[V];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mu = wave_sum(s) * (1.0f / DIM);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[i][r] - mu;
+                q += d * d;
+            }
+        const float var = wave_sum(q) * (1.0f / DIM);
+        const float rs = 1.0f / sqrtf(var + eps);
+        bf16_t* yr = y + row * DIM;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf((v[i][r] - mu) * rs * g[i][r] + b[i][r]);
+            *(bf16x4*)(yr + (i * 64 + lane) * 4) = o;
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (+ residual-stream add).  With xh = (x-mean)*rstd, a = dy*gamma:
+//   dx = rstd * (a - mean(a) - xh * mean(a*xh));   out = dres + dx  (fp32, and a bf16 copy)
+// Column partials per workgroup: dgamma = sum dy*xh, dbeta = sum dy, dxsum = sum out (the bias
+// gradient of the Linear whose output this residual stream is).  partial layout [grid][3][DIM].
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, RowMap xmap,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ dres, int64_t rows,
+                                                      float* __restrict__ dx, bf16_t* __restrict__ dxb, float* __restrict__ partial) {
+    constexpr int DIM = 256 * V;
+    __shared__ float red[4][DIM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 g[V], ag[V], ab[V], as[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        g[i] = *(const f32x4*)(gamma + (i * 64 + lane) * 4);
+        ag[i] = ab[i] = as[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t pr = xmap(row);
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[V], a[V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const f32x4 xv = *(const f32x4*)(x + pr * DIM + (i * 64 + lane) * 4);
+            const bf16x4 dv = *(const bf16x4*)(dy + row * DIM + (i * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = bf2f(dv[r]);
+                xh[i][r] = (xv[r] - mu) * rs;
+                a[i][r] = d * g[i][r];
+                s1 += a[i][r];
+                s2 += a[i][r] * xh[i][r];
+                ag[i][r] += d * xh[i][r];
+                ab[i][r] += d;
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.0f / DIM);
+        const float m2 = wave_sum(s2) * (1.0f / DIM);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = rs * (a[i][r] - m1 - xh[i][r] * m2);
+            if (dres) {
+                const f32x4 rv = *(const f32x4*)(dres + pr * DIM + (i * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += rv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) as[i][r] += o[r];
+            *(f32x4*)(dx + pr * DIM + (i * 64 + lane) * 4) = o;
+            if (dxb) *(bf16x4*)(dxb + pr * DIM + (i * 64 + lane) * 4) = (bf16x4){f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+        }
+    }
+    // cross-wave reduction of the three column partials, one at a time through LDS
+    float* out = partial + (int64_t)blockIdx.x * 3 * DIM;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < V; ++i) *(f32x4*)(&red[wave][(i * 64 + lane) * 4]) = (w == 0 ? ag[i] : (w == 1 ? ab[i] : as[i]));
+        __syncthreads();
+        for (int c = threadIdx.x; c < DIM; c += 256) out[w * DIM + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
+// out[c] (+)= sum_s partial[s * stride + c]
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nslab, int64_t stride, int width,
+                                       float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int i = 0; i < nslab; ++i) s += partial[(int64_t)i * stride + c];
+    out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums of a [rows, width] matrix (bf16 or fp32, optional row map) -> partial[slab][width]
+// workgroup = 4 waves over one 512-column chunk; lane owns 8 consecutive columns
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, int64_t ld, RowMap map, int64_t rows, int width,
+                                                      int rows_per_slab, float* __restrict__ partial) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    const int slab = blockIdx.y;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t r_begin = (int64_t)slab * rows_per_slab;
+    const int64_t r_end = r_begin + rows_per_slab < rows ? r_begin + rows_per_slab : rows;
+    if (c0 < width) {
+        for (int64_t r = r_begin + wave; r < r_end; r += 4) {
+            const T* p = src + map(r) * ld + c0;
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+            } else {
+                const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { acc[k] += v0[k]; acc[4 + k] += v1[k]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = acc[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int gc = blockIdx.x * 512 + c;
+        if (gc < width) partial[(int64_t)slab * width + gc] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
+// out[j, :] = sum_b src[map(b * n + j), :]   (fp32)
+__global__ void batch_sum_kernel(const float* __restrict__ src, RowMap map, int batch, int n, int dim, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over n * dim / 4
+    const int d4 = dim >> 2;
+    if (idx >= (int64_t)n * d4) return;
+    const int j = idx / d4, c = (idx % d4) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < batch; ++b) {
+        const f32x4 v = *(const f32x4*)(src + map((int64_t)b * n + j) * dim + c);
+        s += v;
+    }
+    *(f32x4*)(out + (int64_t)j * dim + c) = s;
+}
+
+// dst[r, :] = bf16(src[map(r), :])
+__global__ void cast_rows_kernel(const float* __restrict__ src, RowMap map, int64_t rows, int dim, bf16_t* __restrict__ dst, int64_t ldd) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows * dim / 4
+    const int d4 = dim >> 2;
+    if (idx >= rows * d4) return;
+    const int64_t r = idx / d4;
+    const int c = (idx % d4) * 4;
+    const f32x4 v = *(const f32x4*)(src + map(r) * dim + c);
+    *(bf16x4*)(dst + r * ldd + c) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+}
+
+// dst[b*seq + off + j, :] = (src ? src[(b*n + j), :] : 0) + (table ? table[j, :] : 0) + (vec ? vec[:] : 0)
+__global__ void assemble_rows_kernel(float* __restrict__ dst, int64_t seq, int64_t off, int batch, int n, int dim,
+                                     const float* __restrict__ src, const float* __restrict__ table, const float* __restrict__ vec) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4 = dim >> 2;
+    if (idx >= (int64_t)batch * n * d4) return;
+    const int c = (idx % d4) * 4;
+    const int64_t r = idx / d4;
+    const int j = r % n;
+    const int64_t b = r / n;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src) v += *(const f32x4*)(src + r * dim + c);
+    if (table) v += *(const f32x4*)(table + (int64_t)j * dim + c);
+    if (vec) v += *(const f32x4*)(vec + c);
+    *(f32x4*)(dst + (b * seq + off + j) * dim + c) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 W[N,K] -> bf16 Wb[N, ldd] and/or bf16 WT[K, lddT] (32x32 LDS transpose)
+// row_perm (optional): packed row r takes source row row_perm[r]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int N, int K, const int32_t* __restrict__ row_perm,
+                                                           bf16_t* __restrict__ wb, int64_t ldd, bf16_t* __restrict__ wt, int64_t lddT) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + i * 8, k = k0 + tx;
+        float v = 0.f;
+        if (n < N && k < K) {
+            const int sn = row_perm ? row_perm[n] : n;
+            v = w[(int64_t)sn * K + k];
+            if (wb) wb[(int64_t)n * ldd + k] = f2bf(v);
+        }
+        tile[ty + i * 8][tx] = v;
+    }
+    if (!wt) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + i * 8, n = n0 + tx;
+        if (n < N && k < K) wt[(int64_t)k * lddT + n] = f2bf(tile[tx][ty + i * 8]);
+    }
+}
+
+}  // namespace
+
+static inline RowMap to_map(vtRowMap m) { return RowMap{m.grp, m.stride, m.off}; }
+
+extern "C" int vt_layernorm_fwd(const float* x, vtRowMap xmap, const float* gamma, const float* beta, float eps, int64_t rows,
+                                int32_t dim, void* y_bf16, float* mean, float* rstd, vtStream stream) {
+    VT_CHECK_ARG(x && gamma && beta && y_bf16 && mean && rstd, "vt_layernorm_fwd: null pointer");
+    VT_CHECK_ARG(rows > 0 && dim % 256 == 0 && dim >= 256 && dim <= 1024, "vt_layernorm_fwd: dim=%d must be 256,512,768 or 1024", dim);
+    const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_FWD(V) hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3(grid), dim3(256), 0, s, x, to_map(xmap), gamma, beta, eps, rows, (bf16_t*)y_bf16, mean, rstd)
+    switch (dim / 256) {
+        case 1: LN_FWD(1); break;
+        case 2: LN_FWD(2); break;
+        case 3: LN_FWD(3); break;
+        default: LN_FWD(4); break;
+    }
+#undef LN_FWD
+    VT_CHECK_LAUNCH("vt_layernorm_fwd");
+    return VT_OK;
+}
+
+#define VT_LN_BWD_GRID 512
+extern "C" size_t vt_layernorm_bwd_workspace_bytes(int32_t dim) { return (size_t)VT_LN_BWD_GRID * 3 * dim * sizeof(float); }
+
+extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xmap, const float* gamma, const float* mean,
+                                const float* rstd, const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* dxsum, void* workspace, vtStream stream) {
+    VT_CHECK_ARG(dy_bf16 && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "vt_layernorm_bwd: null pointer");
+    VT_CHECK_ARG(rows > 0 && dim % 256 == 0 && dim >= 256 && dim <= 1024, "vt_layernorm_bwd: dim=%d must be 256,512,768 or 1024", dim);
+    const int grid = (int)((rows + 3) / 4 < VT_LN_BWD_GRID ? (rows + 3) / 4 : VT_LN_BWD_GRID);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)workspace;
+#define LN_BWD(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy_bf16, x, to_map(xmap), gamma, mean, rstd, dres, rows, dx, (bf16_t*)dx_bf16, part)
+    switch (dim / 256) {
+        case 1: LN_BWD(1); break;
+        case 2: LN_BWD(2); break;
+        case 3: LN_BWD(3); break;
+        default: LN_BWD(4); break;
+    }
+#undef LN_BWD
+    VT_CHECK_LAUNCH("vt_layernorm_bwd");
+    const int rb = (dim + 255) / 256;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, s, part, grid, (int64_t)3 * dim, dim, dgamma);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, s, part + dim, grid, (int64_t)3 * dim, dim, dbeta);
+    if (dxsum) hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, s, part + 2 * dim, grid, (int64_t)3 * dim, dim, dxsum);
+    VT_CHECK_LAUNCH("vt_layernorm_bwd/reduce");
+    return VT_OK;
+}
+
+#define VT_COLSUM_SLABS 64
+extern "C" size_t vt_colsum_workspace_bytes(int32_t width) { return (size_t)VT_COLSUM_SLABS * width * sizeof(float); }
+
+extern "C" int vt_colsum(const void* src, int32_t src_is_bf16, int64_t ld, vtRowMap map, int64_t rows, int32_t width, float* out,
+                         void* workspace, vtStream stream) {
+    VT_CHECK_ARG(src && out && workspace, "vt_colsum: null pointer");
+    VT_CHECK_ARG(rows > 0 && width > 0 && width % 8 == 0 && ld % 8 == 0, "vt_colsum: width/ld must be multiples of 8");
+    int slabs = (int)((rows + 63) / 64);
+    if (slabs > VT_COLSUM_SLABS) slabs = VT_COLSUM_SLABS;
+    const int rps = (int)((rows + slabs - 1) / slabs);
+    const dim3 grid((width + 511) / 512, slabs);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_is_bf16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, ld, to_map(map), rows, width, rps, (float*)workspace);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, to_map(map), rows, width, rps, (float*)workspace);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, s, (const float*)workspace, slabs, (int64_t)width, width, out);
+    VT_CHECK_LAUNCH("vt_colsum");
+    return VT_OK;
+}
+
+extern "C" int vt_batch_sum(const float* src, vtRowMap map, int32_t batch, int32_t n, int32_t dim, float* out, vtStream stream) {
+    VT_CHECK_ARG(src && out && batch > 0 && n > 0 && dim % 4 == 0, "vt_batch_sum: bad arguments");
+    const int64_t total = (int64_t)n * (dim / 4);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, to_map(map), batch, n, dim, out);
+    VT_CHECK_LAUNCH("vt_batch_sum");
+    return VT_OK;
+}
+
+extern "C" int vt_cast_rows(const float* src, vtRowMap map, int64_t rows, int32_t dim, void* dst_bf16, int64_t ldd, vtStream stream) {
+    VT_CHECK_ARG(src && dst_bf16 && rows > 0 && dim % 4 == 0 && ldd % 4 == 0 && ldd >= dim, "vt_cast_rows: bad arguments");
+    const int64_t total = rows * (dim / 4);
+    hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, to_map(map), rows, dim, (bf16_t*)dst_bf16, ldd);
+    VT_CHECK_LAUNCH("vt_cast_rows");
+    return VT_OK;
+}
+
+extern "C" int vt_assemble_rows(float* dst, int64_t seq, int64_t off, int32_t batch, int32_t n, int32_t dim, const float* src,
+                                const float* table, const float* vec, vtStream stream) {
+    VT_CHECK_ARG(dst && batch > 0 && n > 0 && dim % 4 == 0 && off >= 0 && off + n <= seq, "vt_assemble_rows: bad arguments");
+    const int64_t total = (int64_t)batch * n * (dim / 4);
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, seq, off, batch, n, dim, src, table, vec);
+    VT_CHECK_LAUNCH("vt_assemble_rows");
+    return VT_OK;
+}
+
+extern "C" int vt_pack_weight(const float* w, int32_t N, int32_t K, const int32_t* row_perm, void* wb, int64_t ldd, void* wt,
+                              int64_t lddT, vtStream stream) {
+    VT_CHECK_ARG(w && (wb || wt) && N > 0 && K > 0, "vt_pack_weight: bad arguments");
+    VT_CHECK_ARG((!wb || ldd >= K) && (!wt || lddT >= N), "vt_pack_weight: leading dimension too small");
+    const dim3 grid((K + 31) / 32, (N + 31) / 32);
+    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, N, K, row_perm, (bf16_t*)wb, ldd, (bf16_t*)wt, lddT);
+    VT_CHECK_LAUNCH("vt_pack_weight");
+    return VT_OK;
+}

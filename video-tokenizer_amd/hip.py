@@ -1,0 +1,282 @@
+"""ctypes binding of libvt_hip.so (include/vt_hip.h).  PyTorch supplies device memory and the
+stream; nothing here computes on the CPU.  Loading is lazy and LOUD: if the shared library is
+missing (not built), `lib()` raises -- there is no fallback path."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvt_hip.so")
+_lib = None
+
+c_i32, c_i64, c_f32, c_u64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t
+
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_BF16_DGELU = 0, 1, 2, 3
+TN_MAX_GROUP = 8
+
+
+class RowMap(ctypes.Structure):
+    _fields_ = [("grp", c_i32), ("stride", c_i64), ("off", c_i64)]
+
+
+IDENT = RowMap(0, 0, 0)
+
+
+class GemmNT(ctypes.Structure):
+    _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("epi", c_i32), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64), ("bias", c_vp),
+                ("residual", c_vp), ("ldr", c_i64), ("rowmod", c_vp), ("rowmod_period", c_i32), ("aux", c_vp),
+                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32)]
+
+
+class GemmTN(ctypes.Structure):
+    _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("P", c_i32), ("Q", c_i32),
+                ("out", c_vp), ("ldo", c_i64), ("p_lim", c_i32), ("q_lim", c_i32), ("row_perm", c_vp)]
+
+
+# every symbol include/vt_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "vt_abi_version": (c_i32, []),
+    "vt_last_error": (c_i32, [ctypes.c_char_p, c_sz]),
+    "vt_gemm_nt": (c_i32, [ctypes.POINTER(GemmNT), c_vp]),
+    "vt_gemm_tn_grouped": (c_i32, [ctypes.POINTER(GemmTN), c_i32, c_vp]),
+    "vt_layernorm_fwd": (c_i32, [c_vp, RowMap, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "vt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32]),
+    "vt_layernorm_bwd": (c_i32, [c_vp, c_vp, RowMap, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vt_colsum_workspace_bytes": (c_sz, [c_i32]),
+    "vt_colsum": (c_i32, [c_vp, c_i32, c_i64, RowMap, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "vt_batch_sum": (c_i32, [c_vp, RowMap, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vt_cast_rows": (c_i32, [c_vp, RowMap, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "vt_assemble_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "vt_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "vt_patchify": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vt_unpatchify": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vt_attention_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_attention_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
+                              c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vt_vq_backward": (c_i32, [c_vp, c_i64, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                               c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "vt_vq_prep_codebook": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "vt_vq_gather": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
+}
+
+
+def lib():
+    """Load libvt_hip.so (built in-tree by video-tokenizer_amd/build.py).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python video-tokenizer_amd/build.py` "
+                               "(there is no CPU fallback for the tokenizer hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in list(SIGNATURES.items()) + list(ENGINE_SIGNATURES.items()):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+ENGINE_SIGNATURES = {}  # filled by engine.py (vt_tokenizer_* entry points)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        buf = ctypes.create_string_buffer(512)
+        lib().vt_last_error(buf, 512)
+        raise HipError(f"{what} failed ({rc}): {buf.value.decode(errors='replace')}")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL); refuses CPU tensors loudly."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("libvt_hip operates on GPU tensors only (no CPU path)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------
+# thin op-level wrappers (used by tests and by the module for the few ops outside the engine)
+# ---------------------------------------------------------------------------------------------
+
+def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
+            aux=None, omap=None, round_bf16=False, out_rows=None):
+    """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous)."""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+    M, K = A.shape
+    N = B.shape[0]
+    dev = A.device
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty(rows, N, device=dev, dtype=torch.float32 if epi == EPI_F32 else torch.bfloat16)
+    if epi == EPI_BF16_GELU and out2 is None:
+        out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    p = GemmNT()
+    p.A, p.lda, p.B, p.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
+    p.M, p.N, p.K, p.epi = M, N, K, epi
+    p.out, p.ldo = out.data_ptr(), out.stride(0)
+    p.out2, p.ldo2 = (out2.data_ptr(), out2.stride(0)) if out2 is not None else (None, 0)
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.residual, p.ldr = (residual.data_ptr(), residual.stride(0)) if residual is not None else (None, 0)
+    p.rowmod, p.rowmod_period = (rowmod.data_ptr(), rowmod_period) if rowmod is not None else (None, 0)
+    p.aux, p.ldaux = (aux.data_ptr(), aux.stride(0)) if aux is not None else (None, 0)
+    p.omap = omap if omap is not None else IDENT
+    p.round_bf16 = int(round_bf16)
+    check(lib().vt_gemm_nt(ctypes.byref(p), stream()), "vt_gemm_nt")
+    return (out, out2) if epi == EPI_BF16_GELU else out
+
+
+def gemm_tn_grouped(problems):
+    """problems: list of dicts(A=dY [M,P] bf16, B=X [M,Q] bf16, out fp32 [p_lim, >=q_lim], p_lim, q_lim, row_perm)."""
+    arr = (GemmTN * len(problems))()
+    for i, pr in enumerate(problems):
+        A, B, out = pr["A"], pr["B"], pr["out"]
+        g = arr[i]
+        g.A, g.lda, g.B, g.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
+        g.M, g.P, g.Q = A.shape[0], A.shape[1], B.shape[1]
+        g.out, g.ldo = out.data_ptr(), out.stride(0)
+        g.p_lim = pr.get("p_lim", A.shape[1])
+        g.q_lim = pr.get("q_lim", B.shape[1])
+        rp = pr.get("row_perm")
+        g.row_perm = rp.data_ptr() if rp is not None else None
+    check(lib().vt_gemm_tn_grouped(arr, len(problems), stream()), "vt_gemm_tn_grouped")
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def layernorm_fwd(x, gamma, beta, eps, rows=None, xmap=None):
+    dim = x.shape[-1]
+    rows = rows if rows is not None else x.numel() // dim
+    y = torch.empty(rows, dim, device=x.device, dtype=torch.bfloat16)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(lib().vt_layernorm_fwd(ptr(x), xmap or IDENT, ptr(gamma), ptr(beta), eps, rows, dim, ptr(y), ptr(mean), ptr(rstd), stream()), "vt_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, xmap=None, dx=None, dxb=None, want_dxsum=True):
+    rows, dim = dy.shape
+    dev = x.device
+    dx = torch.empty_like(x) if dx is None else dx
+    dxb = torch.empty(x.shape, device=dev, dtype=torch.bfloat16) if dxb is None else dxb
+    dg, db = torch.empty(dim, device=dev), torch.empty(dim, device=dev)
+    ds = torch.empty(dim, device=dev) if want_dxsum else None
+    ws = _ws(lib().vt_layernorm_bwd_workspace_bytes(dim), dev)
+    check(lib().vt_layernorm_bwd(ptr(dy), ptr(x), xmap or IDENT, ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), rows, dim, ptr(dx),
+                                 ptr(dxb), ptr(dg), ptr(db), ptr(ds), ptr(ws), stream()), "vt_layernorm_bwd")
+    return dx, dxb, dg, db, ds
+
+
+def colsum(src, rows=None, rmap=None):
+    width = src.shape[-1]
+    rows = rows if rows is not None else src.numel() // width
+    out = torch.empty(width, device=src.device, dtype=torch.float32)
+    ws = _ws(lib().vt_colsum_workspace_bytes(width), src.device)
+    check(lib().vt_colsum(ptr(src), int(src.dtype == torch.bfloat16), src.stride(-2), rmap or IDENT, rows, width, ptr(out), ptr(ws), stream()), "vt_colsum")
+    return out
+
+
+def batch_sum(src, batch, n, rmap=None):
+    dim = src.shape[-1]
+    out = torch.empty(n, dim, device=src.device, dtype=torch.float32)
+    check(lib().vt_batch_sum(ptr(src), rmap or IDENT, batch, n, dim, ptr(out), stream()), "vt_batch_sum")
+    return out
+
+
+def cast_rows(src, rows=None, rmap=None, ldd=None):
+    dim = src.shape[-1]
+    rows = rows if rows is not None else src.numel() // dim
+    ldd = ldd or dim
+    dst = torch.zeros(rows, ldd, device=src.device, dtype=torch.bfloat16)
+    check(lib().vt_cast_rows(ptr(src), rmap or IDENT, rows, dim, ptr(dst), ldd, stream()), "vt_cast_rows")
+    return dst
+
+
+def assemble_rows(dst, seq, off, batch, n, src=None, table=None, vec=None):
+    check(lib().vt_assemble_rows(ptr(dst), seq, off, batch, n, dst.shape[-1], ptr(src), ptr(table), ptr(vec), stream()), "vt_assemble_rows")
+
+
+def pack_weight(w, row_perm=None, want_t=True, ldd=None, lddT=None, n_pad=None, k_pad=None):
+    w2 = w.reshape(w.shape[0], -1)
+    N, K = w2.shape
+    ldd = ldd or (k_pad or K)
+    lddT = lddT or (n_pad or N)
+    wb = torch.zeros(n_pad or N, ldd, device=w.device, dtype=torch.bfloat16)
+    wt = torch.zeros(k_pad or K, lddT, device=w.device, dtype=torch.bfloat16) if want_t else None
+    check(lib().vt_pack_weight(ptr(w2), N, K, ptr(row_perm), ptr(wb), ldd, ptr(wt), lddT, stream()), "vt_pack_weight")
+    return wb, wt
+
+
+def patchify(video, pt, p):
+    B, C, T, S, _ = video.shape
+    kp = C * pt * p * p
+    nv = (T // pt) * (S // p) ** 2
+    rows = torch.empty(B * nv, kp, device=video.device, dtype=torch.bfloat16)
+    check(lib().vt_patchify(ptr(video), B, C, T, S, pt, p, ptr(rows), stream()), "vt_patchify")
+    return rows
+
+
+def unpatchify(rows, B, C, T, S, pt, p):
+    video = torch.empty(B, C, T, S, S, device=rows.device, dtype=torch.float32)
+    check(lib().vt_unpatchify(ptr(rows), B, C, T, S, pt, p, ptr(video), stream()), "vt_unpatchify")
+    return video
+
+
+def attention_fwd(qkv, B, L, H, hd=64):
+    o = torch.empty(B * L, H * hd, device=qkv.device, dtype=torch.bfloat16)
+    lse2 = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
+    check(lib().vt_attention_fwd(ptr(qkv), B, L, H, hd, ptr(o), ptr(lse2), stream()), "vt_attention_fwd")
+    return o, lse2
+
+
+def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
+    check(lib().vt_attention_bwd(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
+    return dqkv
+
+
+def vq_forward(z_in, codebook, mode, l2_normalized=True, inv_tau=1.0, beta=0.25, codebook_w=1.0, seed=0, ldp=0):
+    """z_in fp32 [N, ldz] (first d columns used). Returns dict of saved tensors."""
+    N = z_in.shape[0]
+    K, d = codebook.shape
+    dev = z_in.device
+    o = {
+        "E": torch.empty(K, d, device=dev), "wnorm": torch.empty(K, device=dev), "zn": torch.empty(N, d, device=dev),
+        "znorm": torch.empty(N, device=dev), "idx": torch.empty(N, device=dev, dtype=torch.int64),
+        "rz": torch.empty(N, d, device=dev), "losses": torch.empty(4, device=dev),
+        "rz_pad": torch.zeros(N, ldp, device=dev, dtype=torch.bfloat16) if ldp else None,
+    }
+    ws = _ws(lib().vt_vq_workspace_bytes(N, K, d), dev)
+    check(lib().vt_vq_forward(ptr(z_in), z_in.stride(0), ptr(codebook), N, K, d, mode, int(l2_normalized), inv_tau, beta, codebook_w,
+                              seed, ptr(o["E"]), ptr(o["wnorm"]), ptr(o["zn"]), ptr(o["znorm"]), ptr(o["idx"]), ptr(o["rz"]),
+                              ptr(o["rz_pad"]), ldp, ptr(o["losses"]), ptr(ws), stream()), "vt_vq_forward")
+    return o
+
+
+def vq_backward(g_rz, gscal, saved, beta=0.25, codebook_w=1.0, l2_normalized=True, ldp=0):
+    zn, E = saved["zn"], saved["E"]
+    N, d = zn.shape
+    K = E.shape[0]
+    dev = zn.device
+    dz = torch.empty(N, d, device=dev)
+    dz_pad = torch.zeros(N, ldp, device=dev, dtype=torch.bfloat16) if ldp else None
+    dW = torch.empty(K, d, device=dev)
+    check(lib().vt_vq_backward(ptr(g_rz), g_rz.stride(0) if g_rz is not None else 0, ptr(gscal), beta, codebook_w, ptr(zn),
+                               ptr(saved["znorm"]), ptr(E), ptr(saved["wnorm"]), ptr(saved["idx"]), N, K, d, int(l2_normalized),
+                               ptr(dz), ptr(dz_pad), ldp, ptr(dW), stream()), "vt_vq_backward")
+    return dz, dz_pad, dW
