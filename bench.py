@@ -1,0 +1,200 @@
+"""Headline benchmark: clips/sec of the LARP tokenizer training step (fwd + bwd, + gradient
+all-reduce when N > 1) on synthetic 16x128x128 clips -- BASELINE.json config[1]:
+cfgs/larp_tokenizer.yaml base geometry (pt2 p16, 12+12 blocks, 1024 latent tokens, d=24, K=8192),
+bs=8 per GPU, bf16 MFMA with fp32 accumulate, `LARPTokenizer(bottleneck_type='vq')`.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = model(data) -> L1 reconstruction loss + 0.1*loss_q (the model-side part of
+trainers/larp_tokenizer_trainer.py:_iter_step; LPIPS/GAN are out of scope) -> backward through the HIP
+engine (-> bucketed RCCL gradient all-reduce) -> fused Adam-free? No: `--optimizer` adds torch Adam.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md (spec, no sparsity)
+
+
+def yaml_model_args(cfg_name):
+    """Model args of the benchmark workload = cfgs/larp_tokenizer.yaml surface with the --opts the SURVEY
+    prescribes (model.name larp_tokenizer, bottleneck_type vq, input_size 128)."""
+    from oracle.larp_oracle import make_cfg
+    c = make_cfg(cfg_name)
+    from tests.test_model_gpu import spec_from_cfg
+    return c, spec_from_cfg(c, stochastic=True)  # yaml default: stochastic sampling, tau 0.03
+
+
+def flops_per_clip(c):
+    """fwd+bwd algorithmic FLOPs per clip: F_blk = 24 L D^2 + 4 L^2 D; bwd = 2x fwd."""
+    D = 768
+    nv = (c["frame_num"] // c["temporal_patch_size"]) * (c["input_size"] // c["patch_size"]) ** 2
+    L = nv + c["bottleneck_token_num"]
+    kp = 3 * c["temporal_patch_size"] * c["patch_size"] ** 2
+    blk = 24 * L * D * D + 4 * L * L * D
+    nq = c["bottleneck_token_num"]
+    fwd = (c["encoder_depth"] + c["decoder_depth"]) * blk + 2 * (2 * nv * kp * D) + 2 * nq * c["codebook_size"] * c["bottleneck_dim"] \
+        + 2 * (2 * nq * D * c["bottleneck_dim"])
+    attn = (c["encoder_depth"] + c["decoder_depth"]) * 4 * L * L * D
+    return 3 * fwd, 3 * attn
+
+
+def time_dominant_kernel(B, c, reps=20):
+    """Roofline of the dominant kernel = the bf16 NT GEMM (gemm_nt_kernel<VT_EPI_BF16>: qkv forward and
+    all three input-gradient GEMMs of a block).  Its launches of one training step are replayed through the
+    C ABI with the same shapes and timed with HIP events on the stream they run on; achieved = sum of
+    algorithmic FLOPs / sum of durations."""
+    import video_tokenizer_amd.hip as hip
+    D = 768
+    nv = (c["frame_num"] // c["temporal_patch_size"]) * (c["input_size"] // c["patch_size"]) ** 2
+    M = B * (nv + c["bottleneck_token_num"])
+    nblk = c["encoder_depth"] + c["decoder_depth"]
+    shapes = [(M, 3 * D, D, nblk), (M, D, 4 * D, nblk), (M, D, D, nblk), (M, D, 3 * D, nblk)]  # qkv fwd, fc1 dgrad, proj dgrad, qkv dgrad
+    tot_f, tot_t, per = 0.0, 0.0, []
+    for (m, n, k, mult) in shapes:
+        A = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+        Bm = (torch.randn(n, k, device="cuda") * 0.03).to(torch.bfloat16)
+        out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            hip.gemm_nt(A, Bm, hip.EPI_BF16, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            hip.gemm_nt(A, Bm, hip.EPI_BF16, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        f = 2.0 * m * n * k
+        per.append({"M": m, "N": n, "K": k, "us": round(t * 1e6, 1), "TFLOPs": round(f / t / 1e12, 1)})
+        tot_f += mult * f
+        tot_t += mult * t
+    return tot_f / tot_t / 1e12, per, tot_t
+
+
+def cpu_baseline(c, sd_seed=7):
+    """The oracle (CPU restatement, fp32, reference semantics) timed on this host's cores: ONE clip of the
+    same workload, forward + backward, stochastic=False index path (multinomial is not the cost)."""
+    from oracle import inputs as gen
+    from oracle import larp_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.init_state_dict(c, seed=sd_seed)
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("_pe") and k != "decoder_patch_query_embed") for k, v in sd.items()}
+    x = torch.from_numpy(gen.video_clips(1, c["frame_num"], c["input_size"], 3))
+    t0 = time.time()
+    out = O.tokenizer_forward(p, c, x, "L")
+    ((out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_q"]).backward()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 clip of the same workload (fwd+bwd, fp32 torch-CPU oracle/larp_oracle.py), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="B")
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--optimizer", action="store_true", help="also run torch.optim.Adam inside the step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    import video_tokenizer_amd as vt
+    from video_tokenizer_amd.parallel import DataParallelTokenizer
+    from oracle import inputs as gen  # synthetic data generator only (inputs, not a checker)
+
+    c, spec = yaml_model_args(a.config)
+    torch.manual_seed(1234 + rank)
+    model = vt.make(spec)
+    with torch.no_grad():  # the reference zero-inits the head (larp_tokenizer.py:327-328) => all-zero output and dead gradients
+        torch.nn.init.xavier_uniform_(model.final_layer.linear.weight)
+    model = model.to(dev).train()
+    net = DataParallelTokenizer(model) if world > 1 else model
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.5, 0.9)) if a.optimizer else None
+
+    B = a.batch
+    x = torch.from_numpy(gen.video_clips(B, c["frame_num"], c["input_size"], 100 + rank)).to(dev)
+
+    def step():
+        out = net(x)
+        loss = (out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_q"]
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in model.parameters():
+                p.grad = None
+        loss.backward()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        clips_s = world * B * a.steps / dt
+        f_clip, f_attn = flops_per_clip(c)
+        res = {
+            "metric": "clips/sec (16x128x128) tokenizer fwd+bwd", "value": round(clips_s, 3), "unit": "clips/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"cfgs/larp_tokenizer.yaml base geometry as LARPTokenizer(bottleneck_type=vq): config {a.config}, "
+                                   f"{c['frame_num']}x{c['input_size']}x{c['input_size']} clips, {B} clips/GPU, "
+                                   f"{c['encoder_depth']}+{c['decoder_depth']} blocks, Nq={c['bottleneck_token_num']}, d={c['bottleneck_dim']}, K={c['codebook_size']}, "
+                                   f"stochastic VQ (tau 0.03), loss = L1 + 0.1*loss_q" + (", Adam" if opt else ""),
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "model_tflops_per_gpu": round(clips_s / world * f_clip / 1e12, 1),
+            "attention_gemm_tflops_per_gpu": round(clips_s / world * f_attn / 1e12, 1),
+        }
+        if not a.no_roofline:
+            ach, per, _ = time_dominant_kernel(B, c)
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<VT_EPI_BF16> (qkv fwd + fc1/proj/qkv dgrad)", "achieved": round(ach, 1),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "per_shape": per, "whole_step_frac": round(clips_s / world * f_clip / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(c)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

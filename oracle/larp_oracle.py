@@ -155,7 +155,7 @@ def encoder_parallel(context, query, p, prefix, depth, num_heads, emu=False):
 
 
 def vq_forward(z, emb_weight, mode="L", l2_normalized=True, beta=0.25, codebook_w=1.0,
-               temperature=0.03, generator=None):
+               temperature=0.03, generator=None, force_idx=None):
     """bottleneck.py:262-324 in fp32.  mode 'L': stochastic=False argmin of the 3-term
     distance (:282-290); 'D': eval-deterministic argmax(softmax(cos/tau)) (:275-278);
     'S': multinomial sample (:280).  Returns the same dict keys."""
@@ -177,6 +177,8 @@ def vq_forward(z, emb_weight, mode="L", l2_normalized=True, beta=0.25, codebook_
         dist = (torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(emb ** 2, dim=1)
                 - 2 * torch.einsum("bd,dn->bn", zf, emb.t()))
         idx = torch.argmin(dist, dim=1)
+    if force_idx is not None:  # test hook: follow a given discrete path (e.g. the GPU's indices)
+        idx = force_idx.reshape(-1).to(torch.int64)
     quantized = F.embedding(idx, emb).view(z.shape)
     loss_commit = ((quantized.detach() - z) ** 2).mean()
     loss_codebook = ((quantized - z.detach()) ** 2).mean()

@@ -1,0 +1,87 @@
+"""Bottleneck + vector quantiser: parameter holders and option surface.
+
+Mirrors /root/reference/models/bottleneck.py: `Bottleneck` (:65-188; in_linear -> regulariser ->
+out_linear, norm='none' only) and `SimpleVectorQuantizer` (:203-344; l2-normalised cosine / L2
+codebook search in three index modes).  State-dict keys: `in_linear.*`, `out_linear.*`,
+`regularizer.embedding.weight`.  Arithmetic: vt_vq_forward / vt_vq_backward + the engine's GEMMs.
+"""
+import torch
+import torch.nn as nn
+
+from .registry import make, register
+
+
+@register("vq")
+class SimpleVectorQuantizer(nn.Module):
+    def __init__(self, dim, codebook_size, commitment_loss_weight=0.25, entropy_loss_weight=0.0,
+                 entropy_loss_temperature=0.01, l2_normalized=False, same_index_shape=True, stochastic=False,
+                 stochastic_temperature=1.0, codebook_loss_weight=1.0, **kwargs):
+        super().__init__()
+        self.codebook_size = codebook_size
+        self.dim = dim
+        self.beta = commitment_loss_weight
+        self.codebook_loss_weight = codebook_loss_weight
+        self.entropy_loss_weight = entropy_loss_weight
+        if entropy_loss_weight > 0:
+            raise NotImplementedError("entropy_loss_weight > 0 is not built (every shipped yaml sets 0.0)")
+        assert isinstance(l2_normalized, bool)
+        self.l2_normalized = l2_normalized
+        self.stochastic = stochastic
+        self.eval_deterministic = False
+        self.default_stochastic_temperature = stochastic_temperature
+        if self.stochastic:
+            assert self.l2_normalized, "Stochastic sampling requires l2 normalization"
+            if stochastic_temperature > 0:
+                self.stochastic_temperature_inv = 1 / stochastic_temperature
+            else:
+                raise NotImplementedError("learnable stochastic temperature is not built")
+        self.embedding = nn.Embedding(self.codebook_size, self.dim)
+        nn.init.kaiming_uniform_(self.embedding.weight)
+        self.same_index_shape = same_index_shape
+        self.entropy_loss_temperature = entropy_loss_temperature
+
+    def set_eval_deterministic(self, deterministic=True):
+        self.eval_deterministic = deterministic
+
+    def set_stochastic_temperature(self, temperature):
+        self.stochastic_temperature_inv = 1 / temperature
+
+    def index_mode(self):
+        """engine vq_mode for the current flags (bottleneck.py:272-290): 0 l2-argmin, 1 cos-argmax, 2 cos-sample."""
+        if not self.stochastic:
+            return 0
+        return 1 if (self.eval_deterministic and not self.training) else 2
+
+    def inv_tau(self):
+        return float(self.stochastic_temperature_inv) if self.stochastic else 1.0
+
+    def forward(self, z):
+        raise RuntimeError("vq runs inside the fused HIP engine (LARPTokenizer); no standalone path")
+
+
+@register("bottleneck")
+class Bottleneck(nn.Module):
+    def __init__(self, bottleneck_dim, input_dim, output_dim, token_nums, norm=None, regularizer=None, param_names=None):
+        super().__init__()
+        self.token_nums = token_nums
+        self.param_names = param_names
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        if bottleneck_dim <= 0:
+            raise NotImplementedError("bottleneck_dim <= 0 (identity projections) is not built")
+        self.bottleneck_dim = bottleneck_dim
+        norm = None if norm is None or norm.lower() in ("no", "none") else norm.lower()
+        if norm is not None:
+            raise NotImplementedError(f"bottleneck norm '{norm}' is not built (the tokenizer yamls use 'none')")
+        self.norm = None
+        if regularizer is None or regularizer["name"].lower() != "vq":
+            raise NotImplementedError("only the 'vq' regularizer is built")
+        self.project_dim = self.bottleneck_dim
+        self.in_linear = nn.Linear(self.input_dim, self.project_dim)
+        self.out_linear = nn.Linear(self.bottleneck_dim, self.output_dim)
+        regularizer["args"]["dim"] = self.bottleneck_dim
+        regularizer["args"]["token_nums"] = self.token_nums
+        self.regularizer = make(regularizer)
+
+    def forward(self, x):
+        raise RuntimeError("bottleneck runs inside the fused HIP engine (LARPTokenizer); no standalone path")

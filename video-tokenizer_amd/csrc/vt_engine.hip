@@ -1,0 +1,461 @@
+// Whole-model engine for the LARP tokenizer step on gfx950: plans one workspace, then enqueues the
+// complete forward (encode -> VQ -> decode) or a range of backward stages on a stream by calling the
+// kernels of this library back to back.  Host code only does pointer arithmetic: no allocation, no
+// synchronisation, no per-op Python -- the sequence is hipGraph-capturable.
+//
+// Follows /root/reference/models/larp_tokenizer.py:400-428 (encode), :456-469 (decode), :489-496
+// (forward); models/transformer.py:62-70 (cat -> blocks -> last len(query) rows); timm Block
+// (pre-LN attention + MLP, see oracle/larp_oracle.py block()); models/bottleneck.py:170-188.
+//
+// HBM layout (all row-major, rows padded to a multiple of 128 and zero-initialised once so that the
+// TN weight-gradient GEMM can contract over padded rows):
+//   residual stream x      fp32 [B*L, D]   one buffer per block boundary (saved for LayerNorm backward)
+//   MFMA operands          bf16            LayerNorm outputs, qkv, attention out, fc1 pre/post GELU
+//   weights                bf16 [N,K] and [K,N] packed copies of the fp32 masters (vt_tokenizer_pack)
+// With 288 GB of HBM3E nothing is recomputed except the attention probabilities.
+#include <vector>
+
+#include "vt_common.h"
+
+namespace {
+
+__global__ void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+// dst[perm[i]] = src[i]
+__global__ void scatter_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[perm[i]] = src[i];
+}
+
+// out[0] = mean_b |x[b*seq + r0, :]|, out[1] = mean_b |x[b*seq + r1, :]|   (bottleneck.py:171-172)
+__global__ void rownorm_mean_kernel(const float* __restrict__ x, int64_t seq, int64_t r0, int64_t r1, int batch, int dim, float* __restrict__ out) {
+    const int which = blockIdx.x;
+    const int64_t r = which == 0 ? r0 : r1;
+    float tot = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float* p = x + ((int64_t)b * seq + r) * dim;
+        float s = 0.f;
+        for (int c = threadIdx.x; c < dim; c += 64) s += p[c] * p[c];
+        s = wave_sum(s);
+        tot += sqrtf(s);
+    }
+    if (threadIdx.x == 0) out[which] = tot / (float)batch;
+}
+
+// dst[r, 0..d) = float(bf16(src[r, 0..d)))   compact copy of the in_linear output ('projected_z')
+__global__ void compact_cols_kernel(const float* __restrict__ src, int64_t lds_, int rows, int d, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * d) dst[i] = src[(int64_t)(i / d) * lds_ + (i % d)];
+}
+
+struct Arena {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+struct BlockBufs {
+    // packed weights
+    size_t qkv_wb, qkv_wt, proj_wb, proj_wt, fc1_wb, fc1_wt, fc2_wb, fc2_wt;
+    // saved activations
+    size_t x_mid, h1, mean1, rstd1, qkv, lse, o, h2, mean2, rstd2, u, g;
+};
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+struct vtTokenizer {
+    vtTokenizerConfig c;
+    int Nv, L, M, Mp, Mv, Mvp, Mq, Mqp, Kp, D3, D4;
+    size_t ws_bytes;
+    std::vector<int32_t> perm_host;  // packed head row j  <-  reference row perm[j]
+    // ---- workspace offsets
+    size_t perm, head_b_perm, dec_query_sum;
+    size_t pe_wb, in_wb, in_wt, out_wb, out_wt, head_wb, head_wt;
+    std::vector<BlockBufs> enc, dec;
+    std::vector<size_t> x_enc, x_dec;  // residual stream at block boundaries (depth+1 each)
+    size_t patches, zb, zproj, vq_E, vq_wnorm, vq_zn, vq_znorm, vq_idx, vq_rz, vq_rzpad, vq_losses, vq_ws, encoded_int;
+    size_t hN, meanH, rstdH, yrows;
+    // backward scratch
+    size_t dX, dXb_a, dXb_b, du, dh, dob, dqkv, delta, ln_ws, cs_ws, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec;
+};
+
+#define WS(T, off) ((T*)((char*)ws + (off)))
+
+static void plan_blocks(vtTokenizer* t, Arena& a, std::vector<BlockBufs>& v, int depth) {
+    const size_t Mp = t->Mp, D = t->c.D, D3 = t->D3, D4 = t->D4;
+    v.resize(depth);
+    for (int i = 0; i < depth; ++i) {
+        BlockBufs& b = v[i];
+        b.qkv_wb = a.take(D3 * D * 2); b.qkv_wt = a.take(D * D3 * 2);
+        b.proj_wb = a.take(D * D * 2); b.proj_wt = a.take(D * D * 2);
+        b.fc1_wb = a.take(D4 * D * 2); b.fc1_wt = a.take(D * D4 * 2);
+        b.fc2_wb = a.take(D * D4 * 2); b.fc2_wt = a.take(D4 * D * 2);
+        b.x_mid = a.take(Mp * D * 4);
+        b.h1 = a.take(Mp * D * 2); b.mean1 = a.take(Mp * 4); b.rstd1 = a.take(Mp * 4);
+        b.qkv = a.take(Mp * D3 * 2); b.lse = a.take((size_t)t->c.B * t->c.H * t->L * 4);
+        b.o = a.take(Mp * D * 2);
+        b.h2 = a.take(Mp * D * 2); b.mean2 = a.take(Mp * 4); b.rstd2 = a.take(Mp * 4);
+        b.u = a.take(Mp * D4 * 2); b.g = a.take(Mp * D4 * 2);
+    }
+}
+
+extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** out) {
+    VT_CHECK_ARG(cfg && out, "vt_tokenizer_create: null pointer");
+    const vtTokenizerConfig& c = *cfg;
+    VT_CHECK_ARG(c.B > 0 && c.C > 0 && c.T > 0 && c.S > 0 && c.pt > 0 && c.p > 0, "vt_tokenizer_create: bad geometry");
+    VT_CHECK_ARG(c.T % c.pt == 0 && c.S % c.p == 0 && c.p % 8 == 0, "vt_tokenizer_create: T%%pt, S%%p, p%%8 must be 0");
+    VT_CHECK_ARG(c.D % 256 == 0 && c.D <= 1024 && c.H * 64 == c.D, "vt_tokenizer_create: D=%d H=%d unsupported (head_dim must be 64, D in 256..1024)", c.D, c.H);
+    VT_CHECK_ARG(c.depth_enc > 0 && c.depth_dec > 0 && c.Nq > 0 && c.K > 0, "vt_tokenizer_create: bad depth/Nq/K");
+    VT_CHECK_ARG(c.d == 8 || c.d == 16 || c.d == 24 || c.d == 32, "vt_tokenizer_create: bottleneck_dim %d unsupported (8,16,24,32)", c.d);
+    VT_CHECK_ARG((c.C * c.pt * c.p * c.p) % 64 == 0, "vt_tokenizer_create: patch volume must be a multiple of 64");
+    vtTokenizer* t = new vtTokenizer();
+    t->c = c;
+    t->Nv = (c.T / c.pt) * (c.S / c.p) * (c.S / c.p);
+    t->L = t->Nv + c.Nq;
+    t->M = c.B * t->L; t->Mp = round_up(t->M, 128);
+    t->Mv = c.B * t->Nv; t->Mvp = round_up(t->Mv, 128);
+    t->Mq = c.B * c.Nq; t->Mqp = round_up(t->Mq, 128);
+    t->Kp = c.C * c.pt * c.p * c.p;
+    t->D3 = 3 * c.D; t->D4 = 4 * c.D;
+    // head row permutation: packed order (c,dt,dy,dx)  <-  reference order (dt,dy,dx,c)  (larp_tokenizer.py:452-453)
+    t->perm_host.resize(t->Kp);
+    for (int ch = 0; ch < c.C; ++ch)
+        for (int dt = 0; dt < c.pt; ++dt)
+            for (int dy = 0; dy < c.p; ++dy)
+                for (int dx = 0; dx < c.p; ++dx) {
+                    const int packed = ((ch * c.pt + dt) * c.p + dy) * c.p + dx;
+                    const int ref = ((dt * c.p + dy) * c.p + dx) * c.C + ch;
+                    t->perm_host[packed] = ref;
+                }
+    Arena a;
+    const size_t D = c.D, Mp = t->Mp, Mvp = t->Mvp, Mqp = t->Mqp, Kp = t->Kp;
+    t->perm = a.take(Kp * 4); t->head_b_perm = a.take(Kp * 4); t->dec_query_sum = a.take((size_t)t->Nv * D * 4);
+    t->pe_wb = a.take(D * Kp * 2);
+    t->in_wb = a.take((size_t)64 * D * 2); t->in_wt = a.take(D * 64 * 2);
+    t->out_wb = a.take(D * 64 * 2); t->out_wt = a.take((size_t)64 * D * 2);
+    t->head_wb = a.take(Kp * D * 2); t->head_wt = a.take(D * Kp * 2);
+    plan_blocks(t, a, t->enc, c.depth_enc);
+    plan_blocks(t, a, t->dec, c.depth_dec);
+    t->x_enc.resize(c.depth_enc + 1);
+    for (auto& x : t->x_enc) x = a.take(Mp * D * 4);
+    t->x_dec.resize(c.depth_dec + 1);
+    for (auto& x : t->x_dec) x = a.take(Mp * D * 4);
+    t->patches = a.take(Mvp * Kp * 2);
+    t->zb = a.take(Mqp * D * 2);
+    t->zproj = a.take(Mqp * 64 * 4);
+    t->vq_E = a.take((size_t)c.K * c.d * 4); t->vq_wnorm = a.take((size_t)c.K * 4);
+    t->vq_zn = a.take(Mqp * c.d * 4); t->vq_znorm = a.take(Mqp * 4); t->vq_idx = a.take(Mqp * 8);
+    t->vq_rz = a.take(Mqp * c.d * 4); t->vq_rzpad = a.take(Mqp * 64 * 2); t->vq_losses = a.take(64);
+    t->vq_ws = a.take(vt_vq_workspace_bytes(t->Mq, c.K, c.d));
+    t->encoded_int = a.take(Mqp * D * 4);
+    t->hN = a.take(Mvp * D * 2); t->meanH = a.take(Mvp * 4); t->rstdH = a.take(Mvp * 4);
+    t->yrows = a.take(Mvp * Kp * 4);
+    t->dX = a.take(Mp * D * 4); t->dXb_a = a.take(Mp * D * 2); t->dXb_b = a.take(Mp * D * 2);
+    t->du = a.take(Mp * t->D4 * 2); t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
+    t->dqkv = a.take(Mp * t->D3 * 2); t->delta = a.take((size_t)c.B * c.H * t->L * 4);
+    t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
+    t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
+    t->dY = a.take(Mvp * Kp * 2); t->dhN = a.take(Mvp * D * 2);
+    t->dEncb = a.take(Mqp * D * 2); t->d_rz = a.take(Mqp * 64 * 4); t->dz_pad = a.take(Mqp * 64 * 2);
+    t->dTok = a.take(Mvp * D * 2);
+    t->tmp_vec = a.take((Kp > (size_t)t->D4 ? Kp : t->D4) * 4);
+    t->ws_bytes = a.off;
+    *out = t;
+    return VT_OK;
+}
+
+extern "C" void vt_tokenizer_destroy(vtTokenizer* t) { delete t; }
+extern "C" size_t vt_tokenizer_workspace_bytes(const vtTokenizer* t) { return t ? t->ws_bytes : 0; }
+extern "C" int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* t) { return t ? 3 + t->c.depth_enc + t->c.depth_dec : 0; }
+
+extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream stream) {
+    VT_CHECK_ARG(t && ws, "vt_tokenizer_init_workspace: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, t->ws_bytes, s) != hipSuccess) { vt_set_error("vt_tokenizer_init_workspace: memset failed"); return VT_ERR_LAUNCH; }
+    if (hipMemcpyAsync(WS(int32_t, t->perm), t->perm_host.data(), (size_t)t->Kp * 4, hipMemcpyHostToDevice, s) != hipSuccess) {
+        vt_set_error("vt_tokenizer_init_workspace: perm upload failed");
+        return VT_ERR_LAUNCH;
+    }
+    return VT_OK;
+}
+
+#define TRY(x)                 \
+    do {                       \
+        int rc__ = (x);        \
+        if (rc__) return rc__; \
+    } while (0)
+
+static int pack_blocks(vtTokenizer* t, const std::vector<BlockBufs>& v, const vtBlockTensors* bl, void* ws, vtStream s) {
+    const int D = t->c.D, D3 = t->D3, D4 = t->D4;
+    for (size_t i = 0; i < v.size(); ++i) {
+        const BlockBufs& b = v[i];
+        TRY(vt_pack_weight(bl[i].qkv_w, D3, D, nullptr, WS(void, b.qkv_wb), D, WS(void, b.qkv_wt), D3, s));
+        TRY(vt_pack_weight(bl[i].proj_w, D, D, nullptr, WS(void, b.proj_wb), D, WS(void, b.proj_wt), D, s));
+        TRY(vt_pack_weight(bl[i].fc1_w, D4, D, nullptr, WS(void, b.fc1_wb), D, WS(void, b.fc1_wt), D4, s));
+        TRY(vt_pack_weight(bl[i].fc2_w, D, D4, nullptr, WS(void, b.fc2_wb), D4, WS(void, b.fc2_wt), D, s));
+    }
+    return VT_OK;
+}
+
+extern "C" int vt_tokenizer_pack(vtTokenizer* t, const vtTokenizerTensors* P, void* ws, vtStream s) {
+    VT_CHECK_ARG(t && P && ws && P->enc_blocks && P->dec_blocks, "vt_tokenizer_pack: null pointer");
+    const vtTokenizerConfig& c = t->c;
+    const int D = c.D, Kp = t->Kp;
+    TRY(vt_pack_weight(P->pe_w, D, Kp, nullptr, WS(void, t->pe_wb), Kp, nullptr, 0, s));
+    TRY(vt_pack_weight(P->in_w, c.d, D, nullptr, WS(void, t->in_wb), D, WS(void, t->in_wt), 64, s));    // [d,D] and [D,64]
+    TRY(vt_pack_weight(P->out_w, D, c.d, nullptr, WS(void, t->out_wb), 64, WS(void, t->out_wt), D, s));  // [D,64] and [64,D]
+    TRY(vt_pack_weight(P->head_w, Kp, D, WS(int32_t, t->perm), WS(void, t->head_wb), D, WS(void, t->head_wt), Kp, s));
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)s, P->head_b, WS(int32_t, t->perm), Kp, WS(float, t->head_b_perm));
+    TRY(vt_assemble_rows(WS(float, t->dec_query_sum), t->Nv, 0, 1, t->Nv, D, nullptr, P->dec_patch_query, P->dec_token_type, s));
+    TRY(pack_blocks(t, t->enc, P->enc_blocks, ws, s));
+    TRY(pack_blocks(t, t->dec, P->dec_blocks, ws, s));
+    VT_CHECK_LAUNCH("vt_tokenizer_pack");
+    return VT_OK;
+}
+
+static vtGemmNT nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epi, void* out, int64_t ldo) {
+    vtGemmNT p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.epi = epi; p.out = out; p.ldo = ldo;
+    return p;
+}
+
+// one timm Block forward: x_in -> x_out (both fp32 [M,D])
+static int block_forward(vtTokenizer* t, const BlockBufs& b, const vtBlockTensors& w, const float* x_in, float* x_out, void* ws, vtStream s) {
+    const vtTokenizerConfig& c = t->c;
+    const int M = t->M, D = c.D, D3 = t->D3, D4 = t->D4;
+    const vtRowMap id = {0, 0, 0};
+    TRY(vt_layernorm_fwd(x_in, id, w.norm1_w, w.norm1_b, 1e-5f, M, D, WS(void, b.h1), WS(float, b.mean1), WS(float, b.rstd1), s));
+    vtGemmNT g = nt(WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_attention_fwd(WS(void, b.qkv), c.B, t->L, c.H, 64, WS(void, b.o), WS(float, b.lse), s));
+    g = nt(WS(void, b.o), D, WS(void, b.proj_wb), D, M, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
+    g.bias = w.proj_b; g.residual = x_in; g.ldr = D;
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_layernorm_fwd(WS(float, b.x_mid), id, w.norm2_w, w.norm2_b, 1e-5f, M, D, WS(void, b.h2), WS(float, b.mean2), WS(float, b.rstd2), s));
+    g = nt(WS(void, b.h2), D, WS(void, b.fc1_wb), D, M, D4, D, VT_EPI_BF16_GELU, WS(void, b.u), D4);
+    g.out2 = WS(void, b.g); g.ldo2 = D4; g.bias = w.fc1_b;
+    TRY(vt_gemm_nt(&g, s));
+    g = nt(WS(void, b.g), D4, WS(void, b.fc2_wb), D4, M, D, D4, VT_EPI_F32, x_out, D);
+    g.bias = w.fc2_b; g.residual = WS(float, b.x_mid); g.ldr = D;
+    TRY(vt_gemm_nt(&g, s));
+    return VT_OK;
+}
+
+extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, const float* video, void* ws,
+                                   const vtTokenizerOutputs* out, uint64_t seed, vtStream s) {
+    VT_CHECK_ARG(t && P && video && ws && out, "vt_tokenizer_encode: null pointer");
+    VT_CHECK_ARG(out->encoded && out->indices && out->losses, "vt_tokenizer_encode: encoded/indices/losses outputs are required");
+    const vtTokenizerConfig& c = t->c;
+    const int D = c.D, L = t->L, Nv = t->Nv, Nq = c.Nq;
+    // 1. patchify + patch-embed GEMM (+bias +sincos PE) written straight into rows [0,Nv) of every sequence
+    TRY(vt_patchify(video, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->patches), s));
+    float* x0 = WS(float, t->x_enc[0]);
+    vtGemmNT g = nt(WS(void, t->patches), t->Kp, WS(void, t->pe_wb), t->Kp, t->Mv, D, t->Kp, VT_EPI_F32, x0, D);
+    g.bias = P->pe_b; g.rowmod = P->enc_patch_pe; g.rowmod_period = Nv; g.omap = vtRowMap{Nv, L, 0};
+    g.round_bf16 = 1;  // conv output is bf16 under autocast before the fp32 PE add
+    TRY(vt_gemm_nt(&g, s));
+    // 2. learned latent queries broadcast into rows [Nv, L)   (larp_tokenizer.py:410, transformer.py:64)
+    TRY(vt_assemble_rows(x0, L, Nv, c.B, Nq, D, nullptr, P->enc_query, nullptr, s));
+    // 3. encoder blocks
+    for (int i = 0; i < c.depth_enc; ++i)
+        TRY(block_forward(t, t->enc[i], P->enc_blocks[i], WS(float, t->x_enc[i]), WS(float, t->x_enc[i + 1]), ws, s));
+    const float* xe = WS(float, t->x_enc[c.depth_enc]);
+    const vtRowMap qmap = {Nq, L, Nv};  // the last Nq rows of every sequence (transformer.py:69)
+    // 4. bottleneck: norm stats, in_linear, VQ, out_linear
+    if (out->input_norms)
+        hipLaunchKernelGGL(rownorm_mean_kernel, dim3(2), dim3(64), 0, (hipStream_t)s, xe, (int64_t)L, (int64_t)Nv, (int64_t)L - 1, c.B, D, out->input_norms);
+    TRY(vt_cast_rows(xe, qmap, t->Mq, D, WS(void, t->zb), D, s));
+    g = nt(WS(void, t->zb), D, WS(void, t->in_wb), D, t->Mq, c.d, D, VT_EPI_F32, WS(void, t->zproj), 64);
+    g.bias = P->in_b; g.round_bf16 = 1;
+    TRY(vt_gemm_nt(&g, s));
+    if (out->projected_z)
+        hipLaunchKernelGGL(compact_cols_kernel, dim3((t->Mq * c.d + 255) / 256), dim3(256), 0, (hipStream_t)s, WS(float, t->zproj), (int64_t)64, t->Mq, c.d, out->projected_z);
+    TRY(vt_vq_forward(WS(float, t->zproj), 64, P->codebook, t->Mq, c.K, c.d, c.vq_mode, c.l2_normalized, c.inv_tau, c.beta, c.codebook_w,
+                      seed, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(int64_t, t->vq_idx),
+                      WS(float, t->vq_rz), WS(void, t->vq_rzpad), 64, WS(float, t->vq_losses), WS(void, t->vq_ws), s));
+    hipStream_t hs = (hipStream_t)s;
+    (void)hipMemcpyAsync(out->indices, WS(void, t->vq_idx), (size_t)t->Mq * 8, hipMemcpyDeviceToDevice, hs);
+    (void)hipMemcpyAsync(out->losses, WS(void, t->vq_losses), 16, hipMemcpyDeviceToDevice, hs);
+    if (out->unregularized_z) (void)hipMemcpyAsync(out->unregularized_z, WS(void, t->vq_zn), (size_t)t->Mq * c.d * 4, hipMemcpyDeviceToDevice, hs);
+    if (out->regularized_z) (void)hipMemcpyAsync(out->regularized_z, WS(void, t->vq_rz), (size_t)t->Mq * c.d * 4, hipMemcpyDeviceToDevice, hs);
+    if (out->emb) (void)hipMemcpyAsync(out->emb, WS(void, t->vq_E), (size_t)c.K * c.d * 4, hipMemcpyDeviceToDevice, hs);
+    g = nt(WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, D, 64, VT_EPI_F32, out->encoded, D);
+    g.bias = P->out_b; g.round_bf16 = 1;
+    TRY(vt_gemm_nt(&g, s));
+    VT_CHECK_LAUNCH("vt_tokenizer_encode");
+    return VT_OK;
+}
+
+extern "C" int vt_tokenizer_codes_to_encoded(vtTokenizer* t, const vtTokenizerTensors* P, const int64_t* indices, void* ws,
+                                             float* encoded, vtStream s) {
+    VT_CHECK_ARG(t && P && indices && ws && encoded, "vt_tokenizer_codes_to_encoded: null pointer");
+    const vtTokenizerConfig& c = t->c;
+    TRY(vt_vq_prep_codebook(P->codebook, c.K, c.d, c.l2_normalized, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(void, t->vq_ws), s));
+    TRY(vt_vq_gather(WS(float, t->vq_E), indices, t->Mq, c.K, c.d, nullptr, WS(void, t->vq_rzpad), 64, s));
+    vtGemmNT g = nt(WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, c.D, 64, VT_EPI_F32, encoded, c.D);
+    g.bias = P->out_b; g.round_bf16 = 1;
+    TRY(vt_gemm_nt(&g, s));
+    return VT_OK;
+}
+
+extern "C" int vt_tokenizer_decode(vtTokenizer* t, const vtTokenizerTensors* P, const float* encoded, void* ws, float* pred, vtStream s) {
+    VT_CHECK_ARG(t && P && encoded && ws && pred, "vt_tokenizer_decode: null pointer");
+    const vtTokenizerConfig& c = t->c;
+    const int D = c.D, L = t->L, Nv = t->Nv, Nq = c.Nq;
+    float* x0 = WS(float, t->x_dec[0]);
+    // decoder sequence = [encoded + latent PE | patch queries (+ token type)]   (larp_tokenizer.py:463-466)
+    TRY(vt_assemble_rows(x0, L, 0, c.B, Nq, D, encoded, P->dec_latent_pe, nullptr, s));
+    TRY(vt_assemble_rows(x0, L, Nq, c.B, Nv, D, nullptr, WS(float, t->dec_query_sum), nullptr, s));
+    for (int i = 0; i < c.depth_dec; ++i)
+        TRY(block_forward(t, t->dec[i], P->dec_blocks[i], WS(float, t->x_dec[i]), WS(float, t->x_dec[i + 1]), ws, s));
+    // head on the last Nv rows: LayerNorm(1e-6) -> Linear (rows permuted to (c,dt,dy,dx)) -> unpatchify
+    const vtRowMap vmap = {Nv, L, Nq};
+    TRY(vt_layernorm_fwd(WS(float, t->x_dec[c.depth_dec]), vmap, P->head_norm_w, P->head_norm_b, 1e-6f, t->Mv, D, WS(void, t->hN),
+                         WS(float, t->meanH), WS(float, t->rstdH), s));
+    vtGemmNT g = nt(WS(void, t->hN), D, WS(void, t->head_wb), D, t->Mv, t->Kp, D, VT_EPI_F32, WS(void, t->yrows), t->Kp);
+    g.bias = WS(float, t->head_b_perm);
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_unpatchify(WS(float, t->yrows), c.B, c.C, c.T, c.S, c.pt, c.p, pred, s));
+    return VT_OK;
+}
+
+static vtGemmTN tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int P, int Q, float* out, int64_t ldo) {
+    vtGemmTN p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.P = P; p.Q = Q; p.out = out; p.ldo = ldo; p.p_lim = P; p.q_lim = Q;
+    return p;
+}
+
+// Backward of one block.  In: dX (fp32) and dXb_a (bf16) hold dL/dx_out.  Out: the same two buffers hold dL/dx_in.
+// prev_bias_grad: where sum_rows(dL/dx_in) goes (= bias gradient of whatever produced x_in), may be NULL.
+static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTensors& w, const vtBlockTensors& gr, const float* x_in,
+                          float* fc2_b_grad_done_marker, float* prev_bias_grad, void* ws, vtStream s) {
+    (void)fc2_b_grad_done_marker;
+    const vtTokenizerConfig& c = t->c;
+    const int M = t->M, Mp = t->Mp, D = c.D, D3 = t->D3, D4 = t->D4;
+    const vtRowMap id = {0, 0, 0};
+    float* dX = WS(float, t->dX);
+    void* dXa = WS(void, t->dXb_a);
+    void* dXm = WS(void, t->dXb_b);
+    // fc2 dgrad fused with GELU': du = (dx_out . W2) * gelu'(u)
+    vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, WS(void, t->du), D4);
+    g.aux = WS(void, b.u); g.ldaux = D4;
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_colsum(WS(void, t->du), 1, D4, id, M, D4, gr.fc1_b, WS(void, t->cs_ws), s));
+    // fc1 dgrad
+    g = nt(WS(void, t->du), D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
+    TRY(vt_gemm_nt(&g, s));
+    // LayerNorm2 backward + residual: dx_mid = dx_out + ln_bwd(dh2) (in place in dX; bf16 copy -> dXm); column sum = proj bias grad
+    TRY(vt_layernorm_bwd(WS(void, t->dh), WS(float, b.x_mid), id, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, M, D, dX, dXm,
+                         gr.norm2_w, gr.norm2_b, gr.proj_b, WS(void, t->ln_ws), s));
+    // proj dgrad
+    g = nt(dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
+    TRY(vt_gemm_nt(&g, s));
+    // attention backward
+    TRY(vt_attention_bwd(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, 64, WS(void, t->dqkv), WS(float, t->delta), s));
+    // qkv dgrad
+    g = nt(WS(void, t->dqkv), D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
+    TRY(vt_gemm_nt(&g, s));
+    // the block's four weight gradients in one grouped launch (432 tiles at D=768: fills the chip, no split-K)
+    vtGemmTN grp[4] = {
+        tn(dXa, D, WS(void, b.g), D4, Mp, D, D4, gr.fc2_w, D4),
+        tn(WS(void, t->du), D4, WS(void, b.h2), D, Mp, D4, D, gr.fc1_w, D),
+        tn(dXm, D, WS(void, b.o), D, Mp, D, D, gr.proj_w, D),
+        tn(WS(void, t->dqkv), D3, WS(void, b.h1), D, Mp, D3, D, gr.qkv_w, D),
+    };
+    TRY(vt_gemm_tn_grouped(grp, 4, s));
+    // LayerNorm1 backward + residual: dx_in = dx_mid + ln_bwd(dh) (in place; bf16 copy -> dXa)
+    TRY(vt_layernorm_bwd(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, dXa, gr.norm1_w,
+                         gr.norm1_b, prev_bias_grad, WS(void, t->ln_ws), s));
+    return VT_OK;
+}
+
+extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P, const float* d_pred, const float* gscal, void* ws,
+                                     const vtTokenizerTensors* G, int32_t stage_begin, int32_t stage_end, vtStream s) {
+    VT_CHECK_ARG(t && P && ws && G && G->enc_blocks && G->dec_blocks, "vt_tokenizer_backward: null pointer");
+    const vtTokenizerConfig& c = t->c;
+    const int nstage = vt_tokenizer_num_backward_stages(t);
+    VT_CHECK_ARG(stage_begin >= 0 && stage_end <= nstage && stage_begin <= stage_end, "vt_tokenizer_backward: bad stage range");
+    const int D = c.D, L = t->L, Nv = t->Nv, Nq = c.Nq, Kp = t->Kp;
+    const vtRowMap id = {0, 0, 0};
+    const vtRowMap vmap = {Nv, L, Nq};   // decoder: last Nv rows
+    const vtRowMap qmap = {Nq, L, Nv};   // encoder: last Nq rows
+    const vtRowMap lmap = {Nq, L, 0};    // decoder: first Nq rows (latents)
+    const vtRowMap tmap = {Nv, L, 0};    // encoder: first Nv rows (video tokens)
+    hipStream_t hs = (hipStream_t)s;
+    float* dX = WS(float, t->dX);
+    for (int st = stage_begin; st < stage_end; ++st) {
+        if (st == 0) {
+            // ---- head: d_pred -> patch rows (c,dt,dy,dx) -> dgrad / wgrad -> LayerNorm backward into the last Nv rows
+            VT_CHECK_ARG(d_pred, "vt_tokenizer_backward: stage 0 needs d_pred");
+            TRY(vt_patchify(d_pred, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->dY), s));
+            vtGemmNT g = nt(WS(void, t->dY), Kp, WS(void, t->head_wt), Kp, t->Mv, D, Kp, VT_EPI_BF16, WS(void, t->dhN), D);
+            TRY(vt_gemm_nt(&g, s));
+            vtGemmTN w = tn(WS(void, t->dY), Kp, WS(void, t->hN), D, t->Mvp, Kp, D, G->head_w, D);
+            w.row_perm = WS(int32_t, t->perm);
+            TRY(vt_gemm_tn_grouped(&w, 1, s));
+            TRY(vt_colsum(WS(void, t->dY), 1, Kp, id, t->Mv, Kp, WS(float, t->tmp_vec), WS(void, t->cs_ws), s));
+            hipLaunchKernelGGL(scatter_f32_kernel, dim3((Kp + 255) / 256), dim3(256), 0, hs, WS(float, t->tmp_vec), WS(int32_t, t->perm), Kp, G->head_b);
+            (void)hipMemsetAsync(dX, 0, (size_t)t->Mp * D * 4, hs);
+            (void)hipMemsetAsync(WS(void, t->dXb_a), 0, (size_t)t->Mp * D * 2, hs);
+            // rows < Nq of the last decoder block's output are dropped by the slice => zero gradient
+            TRY(vt_layernorm_bwd(WS(void, t->dhN), WS(float, t->x_dec[c.depth_dec]), vmap, P->head_norm_w, WS(float, t->meanH), WS(float, t->rstdH),
+                                 nullptr, t->Mv, D, dX, WS(void, t->dXb_a), G->head_norm_w, G->head_norm_b,
+                                 nullptr, WS(void, t->ln_ws), s));
+            // fc2 bias grad of the last decoder block = column sum of dL/dx_out (all rows; zero rows add nothing)
+            TRY(vt_colsum(dX, 0, D, id, t->M, D, G->dec_blocks[c.depth_dec - 1].fc2_b, WS(void, t->cs_ws), s));
+        } else if (st <= c.depth_dec) {
+            const int i = c.depth_dec - st;  // decoder blocks, last first
+            float* prev = i > 0 ? G->dec_blocks[i - 1].fc2_b : nullptr;
+            TRY(block_backward(t, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), nullptr, prev, ws, s));
+        } else if (st == c.depth_dec + 1) {
+            // ---- bottleneck.  dX holds dL/d(decoder input sequence)
+            if (G->dec_token_type) TRY(vt_colsum(dX, 0, D, vmap, t->Mv, D, G->dec_token_type, WS(void, t->cs_ws), s));
+            TRY(vt_cast_rows(dX, lmap, t->Mq, D, WS(void, t->dEncb), D, s));  // d encoded (bf16 under autocast)
+            TRY(vt_colsum(WS(void, t->dEncb), 1, D, id, t->Mq, D, G->out_b, WS(void, t->cs_ws), s));
+            // out_linear: dgrad -> d regularized_z [Mq,64]; wgrad -> dW_out [D,d]
+            vtGemmNT g = nt(WS(void, t->dEncb), D, WS(void, t->out_wt), D, t->Mq, 64, D, VT_EPI_F32, WS(void, t->d_rz), 64);
+            TRY(vt_gemm_nt(&g, s));
+            vtGemmTN w = tn(WS(void, t->dEncb), D, WS(void, t->vq_rzpad), 64, t->Mqp, D, 64, G->out_w, c.d);
+            w.q_lim = c.d;
+            TRY(vt_gemm_tn_grouped(&w, 1, s));
+            // VQ backward: straight-through + commitment to z, codebook loss to the embedding
+            TRY(vt_vq_backward(WS(float, t->d_rz), 64, gscal, c.beta, c.codebook_w, WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(float, t->vq_E),
+                               WS(float, t->vq_wnorm), WS(int64_t, t->vq_idx), t->Mq, c.K, c.d, c.l2_normalized, nullptr, WS(void, t->dz_pad), 64,
+                               G->codebook, s));
+            // in_linear: bias grad, wgrad, dgrad scattered into the last Nq rows of the encoder output gradient
+            TRY(vt_colsum(WS(void, t->dz_pad), 1, 64, id, t->Mq, 64, WS(float, t->tmp_vec), WS(void, t->cs_ws), s));
+            (void)hipMemcpyAsync(G->in_b, WS(void, t->tmp_vec), (size_t)c.d * 4, hipMemcpyDeviceToDevice, hs);
+            w = tn(WS(void, t->dz_pad), 64, WS(void, t->zb), D, t->Mqp, 64, D, G->in_w, D);
+            w.p_lim = c.d;
+            TRY(vt_gemm_tn_grouped(&w, 1, s));
+            (void)hipMemsetAsync(dX, 0, (size_t)t->Mp * D * 4, hs);
+            (void)hipMemsetAsync(WS(void, t->dXb_a), 0, (size_t)t->Mp * D * 2, hs);
+            g = nt(WS(void, t->dz_pad), 64, WS(void, t->in_wt), 64, t->Mq, D, 64, VT_EPI_F32, dX, D);
+            g.out2 = WS(void, t->dXb_a); g.ldo2 = D; g.omap = qmap;
+            TRY(vt_gemm_nt(&g, s));
+            TRY(vt_colsum(dX, 0, D, id, t->M, D, G->enc_blocks[c.depth_enc - 1].fc2_b, WS(void, t->cs_ws), s));
+        } else if (st <= c.depth_dec + 1 + c.depth_enc) {
+            const int i = c.depth_enc - (st - c.depth_dec - 1);
+            float* prev = i > 0 ? G->enc_blocks[i - 1].fc2_b : nullptr;
+            TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), nullptr, prev, ws, s));
+        } else {
+            // ---- patch embed + learned queries.  dX holds dL/d(encoder input sequence)
+            TRY(vt_batch_sum(dX, qmap, c.B, Nq, D, G->enc_query, s));
+            TRY(vt_cast_rows(dX, tmap, t->Mv, D, WS(void, t->dTok), D, s));
+            TRY(vt_colsum(WS(void, t->dTok), 1, D, id, t->Mv, D, G->pe_b, WS(void, t->cs_ws), s));
+            vtGemmTN w = tn(WS(void, t->dTok), D, WS(void, t->patches), Kp, t->Mvp, D, Kp, G->pe_w, Kp);
+            TRY(vt_gemm_tn_grouped(&w, 1, s));
+        }
+    }
+    VT_CHECK_LAUNCH("vt_tokenizer_backward");
+    return VT_OK;
+}

@@ -1,0 +1,317 @@
+"""Host side of the fused tokenizer engine: binds a LARPTokenizer's parameters to the C ABI
+(vt_tokenizer_* in include/vt_hip.h) and exposes forward/backward as ONE torch.autograd.Function.
+
+PyTorch is plumbing here: it owns the device memory (parameters, one flat gradient buffer, the
+engine workspace, the outputs) and the stream; every FLOP of the step runs in libvt_hip.so.
+Gradients are written by the kernels straight into slices of one flat fp32 buffer laid out in the
+order backward produces them, so a data-parallel reducer can all-reduce finished slices while later
+stages are still running (parallel.py).
+"""
+import ctypes
+
+import torch
+
+from . import hip
+
+
+def _flat_order(model):
+    """(name, tensor, stage) for every trainable parameter in the order the backward stages write
+    their gradients.  Stage numbering = vt_tokenizer_backward: 0 head, 1..depth_dec decoder blocks
+    (last first), then bottleneck, encoder blocks (last first), patch-embed."""
+    de, dd = model.encoder.depth, model.decoder.depth
+    out = []
+
+    def blk(side, i, stage, with_fc2_b_of=None):
+        b = getattr(model, side).blocks[i]
+        pre = f"{side}.blocks.{i}."
+        for n, p in (("norm1.weight", b.norm1.weight), ("norm1.bias", b.norm1.bias), ("attn.qkv.weight", b.attn.qkv.weight),
+                     ("attn.proj.weight", b.attn.proj.weight), ("attn.proj.bias", b.attn.proj.bias), ("norm2.weight", b.norm2.weight),
+                     ("norm2.bias", b.norm2.bias), ("mlp.fc1.weight", b.mlp.fc1.weight), ("mlp.fc1.bias", b.mlp.fc1.bias),
+                     ("mlp.fc2.weight", b.mlp.fc2.weight)):
+            out.append((pre + n, p, stage))
+
+    def fc2b(side, i, stage):
+        out.append((f"{side}.blocks.{i}.mlp.fc2.bias", getattr(model, side).blocks[i].mlp.fc2.bias, stage))
+
+    fl = model.final_layer
+    out += [("final_layer.linear.weight", fl.linear.weight, 0), ("final_layer.linear.bias", fl.linear.bias, 0),
+            ("final_layer.norm_final.weight", fl.norm_final.weight, 0), ("final_layer.norm_final.bias", fl.norm_final.bias, 0)]
+    fc2b("decoder", dd - 1, 0)
+    for st in range(1, dd + 1):
+        i = dd - st
+        blk("decoder", i, st)
+        if i > 0:
+            fc2b("decoder", i - 1, st)
+    st = dd + 1
+    bt = model.bottleneck
+    if model.use_decoder_patch_query_token_type_embed:
+        out.append(("decoder_patch_query_token_type_embed", model.decoder_patch_query_token_type_embed, st))
+    out += [("bottleneck.out_linear.bias", bt.out_linear.bias, st), ("bottleneck.out_linear.weight", bt.out_linear.weight, st),
+            ("bottleneck.regularizer.embedding.weight", bt.regularizer.embedding.weight, st),
+            ("bottleneck.in_linear.bias", bt.in_linear.bias, st), ("bottleneck.in_linear.weight", bt.in_linear.weight, st)]
+    fc2b("encoder", de - 1, st)
+    for k in range(1, de + 1):
+        i = de - k
+        blk("encoder", i, st + k)
+        if i > 0:
+            fc2b("encoder", i - 1, st + k)
+    last = st + de + 1
+    out += [("encoder_latent_query_embed", model.encoder_latent_query_embed, last),
+            ("x_embedder.proj.bias", model.x_embedder.proj.bias, last), ("x_embedder.proj.weight", model.x_embedder.proj.weight, last)]
+    return out
+
+
+class _Tensors:
+    """ctypes vtTokenizerTensors over a name->tensor mapping (parameters or gradient views)."""
+
+    def __init__(self, model, get):
+        de, dd = model.encoder.depth, model.decoder.depth
+        self.enc = (hip.BlockTensors * de)()
+        self.dec = (hip.BlockTensors * dd)()
+        names = {"norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "qkv_w": "attn.qkv.weight", "proj_w": "attn.proj.weight",
+                 "proj_b": "attn.proj.bias", "norm2_w": "norm2.weight", "norm2_b": "norm2.bias", "fc1_w": "mlp.fc1.weight",
+                 "fc1_b": "mlp.fc1.bias", "fc2_w": "mlp.fc2.weight", "fc2_b": "mlp.fc2.bias"}
+        for side, arr, depth in (("encoder", self.enc, de), ("decoder", self.dec, dd)):
+            for i in range(depth):
+                for f, n in names.items():
+                    setattr(arr[i], f, get(f"{side}.blocks.{i}.{n}"))
+        t = hip.TokenizerTensors()
+        t.pe_w, t.pe_b = get("x_embedder.proj.weight"), get("x_embedder.proj.bias")
+        t.enc_patch_pe = get("encoder_patch_pe")
+        t.enc_query = get("encoder_latent_query_embed")
+        t.dec_latent_pe = get("decoder_latent_pe")
+        t.dec_patch_query = get("decoder_patch_query_embed")
+        t.dec_token_type = get("decoder_patch_query_token_type_embed")
+        t.in_w, t.in_b = get("bottleneck.in_linear.weight"), get("bottleneck.in_linear.bias")
+        t.out_w, t.out_b = get("bottleneck.out_linear.weight"), get("bottleneck.out_linear.bias")
+        t.codebook = get("bottleneck.regularizer.embedding.weight")
+        t.head_norm_w, t.head_norm_b = get("final_layer.norm_final.weight"), get("final_layer.norm_final.bias")
+        t.head_w, t.head_b = get("final_layer.linear.weight"), get("final_layer.linear.bias")
+        t.enc_blocks = ctypes.cast(self.enc, ctypes.POINTER(hip.BlockTensors))
+        t.dec_blocks = ctypes.cast(self.dec, ctypes.POINTER(hip.BlockTensors))
+        self.struct = t
+
+
+class _State:
+    """One engine handle + workspace for a fixed (batch, frames, size, vq mode) geometry."""
+
+    def __init__(self, engine, key, cfg, device):
+        self.key = key
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        hip.check(hip.lib().vt_tokenizer_create(ctypes.byref(cfg), ctypes.byref(h)), "vt_tokenizer_create")
+        self.handle = h
+        nbytes = hip.lib().vt_tokenizer_workspace_bytes(h)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        hip.check(hip.lib().vt_tokenizer_init_workspace(h, hip.ptr(self.ws), hip.stream()), "vt_tokenizer_init_workspace")
+        self.nstages = hip.lib().vt_tokenizer_num_backward_stages(h)
+        self.packed_version = None
+        self.fwd_id = 0
+
+    def __del__(self):
+        try:
+            if self.handle:
+                hip.lib().vt_tokenizer_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class TokenizerEngine:
+    def __init__(self, model):
+        self.model = model
+        self.states = {}
+        self.flat_grad = None
+        self.order = None
+        self.segments = None  # stage -> (lo, hi) element range of the flat gradient buffer
+        self.reducer = None   # set by parallel.DataParallelTokenizer
+        self.seed_counter = 0
+
+    # ------------------------------------------------------------------ parameters / gradients
+    def _named(self):
+        m = self.model
+        d = dict(m.named_parameters())
+        d.update(dict(m.named_buffers()))
+        return d
+
+    def param_struct(self):
+        named = self._named()
+
+        def get(name):
+            t = named.get(name)
+            if t is None:
+                return None
+            if not t.is_cuda:
+                raise hip.HipError(f"{name} is on {t.device}: the tokenizer hot path runs on the GPU only (no CPU fallback)")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise hip.HipError(f"{name}: fp32 contiguous master weights required (got {t.dtype})")
+            return t.data_ptr()
+        return _Tensors(self.model, get)
+
+    def ensure_flat_grad(self, device):
+        if self.flat_grad is not None and self.flat_grad.device == device:
+            return
+        self.order = _flat_order(self.model)
+        total, segs, views, off = 0, {}, {}, 0
+        for name, p, st in self.order:
+            n = p.numel()
+            lo, hi = segs.get(st, (off, off))
+            segs[st] = (lo, off + n)
+            off += n
+        total = off
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        off, offsets = 0, {}
+        for name, p, st in self.order:
+            views[name] = self.flat_grad[off:off + p.numel()].view(p.shape)
+            offsets[name] = off
+            off += p.numel()
+        self.grad_views = views
+        self.grad_offsets = offsets
+        self.segments = segs
+        self.grad_struct = _Tensors(self.model, lambda n: views[n].data_ptr() if n in views else None)
+
+    def params_version(self):
+        return sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.model.buffers())
+
+    # ------------------------------------------------------------------ states
+    def state_for(self, B, T, S, device):
+        m = self.model
+        vq = m.bottleneck.regularizer
+        mode = vq.index_mode()
+        key = (B, T, S, mode, vq.inv_tau(), str(device))
+        st = self.states.get(key)
+        if st is None:
+            c = hip.TokenizerConfig()
+            c.B, c.C, c.T, c.S, c.pt, c.p = B, m.in_channels, T, S, m.temporal_patch_size, m.patch_size
+            c.D, c.H, c.depth_enc, c.depth_dec = m.encoder_hidden_size, m.encoder_num_heads, m.encoder.depth, m.decoder.depth
+            c.Nq, c.d, c.K = m.bottleneck_token_num, m.bottleneck_dim, m.codebook_size
+            c.vq_mode, c.l2_normalized = mode, int(vq.l2_normalized)
+            c.inv_tau, c.beta, c.codebook_w = vq.inv_tau(), vq.beta, vq.codebook_loss_weight
+            st = _State(self, key, c, device)
+            self.states[key] = st
+        return st
+
+    def ensure_packed(self, st, pstruct):
+        v = self.params_version()
+        if st.packed_version != v:
+            hip.check(hip.lib().vt_tokenizer_pack(st.handle, ctypes.byref(pstruct.struct), hip.ptr(st.ws), hip.stream()), "vt_tokenizer_pack")
+            st.packed_version = v
+
+    def next_seed(self):
+        self.seed_counter += 1
+        base = int(torch.initial_seed()) & 0xFFFFFFFF
+        return (base << 32) | (self.seed_counter & 0xFFFFFFFF)
+
+
+def _outputs(m, B, device):
+    Nq, D, d, K = m.bottleneck_token_num, m.decoder_hidden_size, m.bottleneck_dim, m.codebook_size
+    f = dict(device=device, dtype=torch.float32)
+    return {
+        "encoded": torch.empty(B, Nq, D, **f), "indices": torch.empty(B, Nq, device=device, dtype=torch.int64),
+        "projected_z": torch.empty(B, Nq, d, **f), "unregularized_z": torch.empty(B, Nq, d, **f),
+        "regularized_z": torch.empty(B, Nq, d, **f), "emb": torch.empty(K, d, **f),
+        "losses": torch.empty(4, **f), "input_norms": torch.empty(2, **f),
+    }
+
+
+def _out_struct(o, pred=None):
+    s = hip.TokenizerOutputs()
+    s.pred_frames = pred.data_ptr() if pred is not None else None
+    for k in ("encoded", "indices", "projected_z", "unregularized_z", "regularized_z", "emb", "losses", "input_norms"):
+        setattr(s, k, o[k].data_ptr())
+    return s
+
+
+def _check_video(m, x):
+    if not x.is_cuda:
+        raise hip.HipError("LARPTokenizer: input is on the CPU; the hot path runs on MI355X only (no CPU fallback)")
+    assert x.dim() == 5 and x.shape[1] == m.in_channels, "data: video in shape (b, c, t, h, w)"
+    m.x_embedder.check_input(x)
+    return x.contiguous().float()
+
+
+def run_encode(engine, x):
+    m = engine.model
+    x = _check_video(m, x)
+    B, _, T, S, _ = x.shape
+    st = engine.state_for(B, T, S, x.device)
+    ps = engine.param_struct()
+    engine.ensure_packed(st, ps)
+    o = _outputs(m, B, x.device)
+    os_ = _out_struct(o)
+    hip.check(hip.lib().vt_tokenizer_encode(st.handle, ctypes.byref(ps.struct), hip.ptr(x), hip.ptr(st.ws), ctypes.byref(os_),
+                                            engine.next_seed(), hip.stream()), "vt_tokenizer_encode")
+    st.fwd_id += 1
+    return st, ps, o
+
+
+def run_decode(engine, st, ps, encoded, B, T, S):
+    m = engine.model
+    pred = torch.empty(B, m.out_channels, T, S, S, device=encoded.device, dtype=torch.float32)
+    hip.check(hip.lib().vt_tokenizer_decode(st.handle, ctypes.byref(ps.struct), hip.ptr(encoded), hip.ptr(st.ws), hip.ptr(pred), hip.stream()),
+              "vt_tokenizer_decode")
+    return pred
+
+
+class TokenizerFunction(torch.autograd.Function):
+    """forward(video) -> (pred_frames, losses[4], + non-differentiable VQ outputs); backward fills
+    the flat gradient buffer through vt_tokenizer_backward and hands views of it to autograd."""
+
+    @staticmethod
+    def forward(ctx, engine, x, *params):
+        m = engine.model
+        st, ps, o = run_encode(engine, x)
+        B, _, T, S, _ = x.shape
+        pred = run_decode(engine, st, ps, o["encoded"], B, T, S)
+        ctx.engine, ctx.st, ctx.fwd_id = engine, st, st.fwd_id
+        ctx.n_params = len(params)
+        ctx.x_shape = x.shape
+        nd = (o["encoded"], o["indices"], o["projected_z"], o["unregularized_z"], o["regularized_z"], o["emb"], o["input_norms"])
+        ctx.mark_non_differentiable(*nd)
+        return (pred, o["losses"]) + nd
+
+    @staticmethod
+    def backward(ctx, d_pred, d_losses, *unused):
+        engine, st = ctx.engine, ctx.st
+        if st.fwd_id != ctx.fwd_id:
+            raise hip.HipError("LARPTokenizer.backward: the engine workspace was overwritten by a later forward with the same "
+                               "geometry; run backward before the next forward")
+        dev = st.ws.device
+        engine.ensure_flat_grad(dev)
+        if d_pred is None:
+            d_pred = torch.zeros(ctx.x_shape, device=dev, dtype=torch.float32)
+        d_pred = d_pred.contiguous().float()
+        gscal = d_losses.contiguous().float() if d_losses is not None else None
+        ps = engine.param_struct()
+        lib = hip.lib()
+        red = engine.reducer
+        named = dict(engine.model.named_parameters())
+        # gradient accumulation: parameters whose .grad already IS a view of the flat buffer (no zero_grad(set_to_none=True)
+        # since the last step) keep their old values: save them, let the kernels overwrite, add back afterwards.
+        lo_ptr, hi_ptr = engine.flat_grad.data_ptr(), engine.flat_grad.data_ptr() + engine.flat_grad.numel() * 4
+        aliased = {n for n in engine.apply_names if named[n].grad is not None and lo_ptr <= named[n].grad.data_ptr() < hi_ptr}
+        saved = engine.flat_grad.clone() if aliased else None
+        for stage in range(st.nstages):
+            hip.check(lib.vt_tokenizer_backward(st.handle, ctypes.byref(ps.struct), hip.ptr(d_pred), hip.ptr(gscal), hip.ptr(st.ws),
+                                                ctypes.byref(engine.grad_struct.struct), stage, stage + 1, hip.stream()), "vt_tokenizer_backward")
+            if red is not None:
+                red.segment_ready(engine.flat_grad, *engine.segments[stage])
+        if red is not None:
+            red.finish()
+        if saved is not None:
+            engine.flat_grad.add_(saved)
+        grads = []
+        # autograd wants gradients in the order the parameters were passed to apply()
+        for name in engine.apply_names:
+            if not named[name].requires_grad or name in aliased:
+                grads.append(None)  # aliased: .grad already shows old + new through the flat buffer
+            elif saved is not None:
+                grads.append(engine.grad_views[name] - saved[engine.grad_offsets[name]:engine.grad_offsets[name] + named[name].numel()].view_as(named[name]))
+            else:
+                grads.append(engine.grad_views[name])
+        return (None, None) + tuple(grads)
+
+
+def apply(engine, x):
+    order = _flat_order(engine.model)
+    engine.apply_names = [n for n, _, _ in order]
+    return TokenizerFunction.apply(engine, x, *[p for _, p, _ in order])

@@ -64,6 +64,48 @@ SIGNATURES = {
 }
 
 
+class TokenizerConfig(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("B", "C", "T", "S", "pt", "p", "D", "H", "depth_enc", "depth_dec", "Nq", "d", "K", "vq_mode", "l2_normalized")] + \
+               [(n, c_f32) for n in ("inv_tau", "beta", "codebook_w")]
+
+
+BLOCK_FIELDS = ("norm1_w", "norm1_b", "qkv_w", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class BlockTensors(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in BLOCK_FIELDS]
+
+
+TENSOR_FIELDS = ("pe_w", "pe_b", "enc_patch_pe", "enc_query", "dec_latent_pe", "dec_patch_query", "dec_token_type", "in_w", "in_b",
+                 "out_w", "out_b", "codebook", "head_norm_w", "head_norm_b", "head_w", "head_b")
+
+
+class TokenizerTensors(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in TENSOR_FIELDS] + [("enc_blocks", ctypes.POINTER(BlockTensors)), ("dec_blocks", ctypes.POINTER(BlockTensors))]
+
+
+OUTPUT_FIELDS = ("pred_frames", "encoded", "indices", "projected_z", "unregularized_z", "regularized_z", "emb", "losses", "input_norms")
+
+
+class TokenizerOutputs(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in OUTPUT_FIELDS]
+
+
+_TT = ctypes.POINTER(TokenizerTensors)
+ENGINE_SIGNATURES = {
+    "vt_tokenizer_create": (c_i32, [ctypes.POINTER(TokenizerConfig), ctypes.POINTER(c_vp)]),
+    "vt_tokenizer_destroy": (None, [c_vp]),
+    "vt_tokenizer_workspace_bytes": (c_sz, [c_vp]),
+    "vt_tokenizer_init_workspace": (c_i32, [c_vp, c_vp, c_vp]),
+    "vt_tokenizer_pack": (c_i32, [c_vp, _TT, c_vp, c_vp]),
+    "vt_tokenizer_encode": (c_i32, [c_vp, _TT, c_vp, c_vp, ctypes.POINTER(TokenizerOutputs), c_u64, c_vp]),
+    "vt_tokenizer_decode": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
+    "vt_tokenizer_codes_to_encoded": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
+    "vt_tokenizer_num_backward_stages": (c_i32, [c_vp]),
+    "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, c_vp]),
+}
+
+
 def lib():
     """Load libvt_hip.so (built in-tree by video-tokenizer_amd/build.py).  Raises if absent."""
     global _lib
@@ -80,7 +122,6 @@ def lib():
     return _lib
 
 
-ENGINE_SIGNATURES = {}  # filled by engine.py (vt_tokenizer_* entry points)
 
 
 class HipError(RuntimeError):

@@ -1,0 +1,279 @@
+"""`larp_tokenizer`: the LARP video tokenizer behind the reference's model-registry interface.
+
+Drop-in for /root/reference/models/larp_tokenizer.py `LARPTokenizer` (:44-496) with
+bottleneck_type='vq': same constructor keywords (unknown extras are accepted and ignored so that
+`from_checkpoint(cls(**ckpt['model']['args']))` works with the yaml's extra keys), same state-dict
+keys/shapes, same output-dict keys, same public methods (encode / decode / encode_eval /
+decode_eval / decode_from_bottleneck / from_checkpoint / set_vq_eval_deterministic ...).
+forward/backward run in the fused HIP engine (engine.py -> libvt_hip.so); there is no CPU path.
+"""
+import itertools
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as _engine
+from . import hip
+from . import registry
+from .embed import PatchEmbed3D, get_1d_sincos_pos_embed_from_grid, get_3d_sincos_pos_embed
+from .registry import register
+
+
+class OutputLayer(nn.Module):
+    """LayerNorm(eps 1e-6) + Linear(hidden, pt*p*p*c) parameter holder (larp_tokenizer.py:31-41)."""
+
+    def __init__(self, hidden_size, temporal_patch_size, patch_size, out_channels):
+        super().__init__()
+        self.norm_final = nn.LayerNorm(hidden_size, eps=1e-6)
+        self.linear = nn.Linear(hidden_size, temporal_patch_size * patch_size * patch_size * out_channels, bias=True)
+
+
+@register("larp_tokenizer")
+class LARPTokenizer(nn.Module):
+    output_format = "bcthw"
+
+    def __init__(self, bottleneck, prior_model=None, bottleneck_token_num=1024, input_size=128, frame_num=16,
+                 temporal_patch_size=4, patch_size=8, decoder_temporal_patch_size=4, decoder_patch_size=8, in_channels=3,
+                 bottleneck_type="auto", transformer_name="transformer_encoder_parallel", encoder_name=None, decoder_name=None,
+                 latent_pe_scale_factor=10000, query_init_std=0.02, encoder_hidden_size=768, decoder_hidden_size=768,
+                 encoder_num_heads=12, decoder_num_heads=12, encoder_depth=6, decoder_depth=6, train_type="simple",
+                 learned_encoder_patch_pe=False, learned_encoder_latent_query_embed=True, learned_decoder_latent_pe=False,
+                 learned_decoder_patch_query_embed=False, use_encoder_patch_token_type_embed=False,
+                 use_encoder_latent_query_token_type_embed=False, use_decoder_latent_token_type_embed=False,
+                 use_decoder_patch_query_token_type_embed=False, encoder_query_gaussian_init=True, **ignored):
+        super().__init__()
+        # `ignored`: yaml keys the reference class does not take (e.g. use_pe, cfgs/larp_tokenizer.yaml:75)
+        if bottleneck_type != "vq":
+            raise NotImplementedError(f"bottleneck_type='{bottleneck_type}': this build implements the 'vq' bottleneck "
+                                      "(pass model.args.bottleneck_type vq); 'auto' builds no bottleneck in the reference either")
+        if train_type != "simple":
+            raise NotImplementedError("train_type 'mrope' is out of scope")
+        unsupported = dict(learned_encoder_patch_pe=learned_encoder_patch_pe, learned_decoder_latent_pe=learned_decoder_latent_pe,
+                           learned_decoder_patch_query_embed=learned_decoder_patch_query_embed,
+                           use_encoder_patch_token_type_embed=use_encoder_patch_token_type_embed,
+                           use_encoder_latent_query_token_type_embed=use_encoder_latent_query_token_type_embed,
+                           use_decoder_latent_token_type_embed=use_decoder_latent_token_type_embed)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad or not learned_encoder_latent_query_embed:
+            raise NotImplementedError(f"option(s) {bad or ['learned_encoder_latent_query_embed=False']} are not built "
+                                      "(the shipped yaml uses fixed sin-cos PEs + learned latent queries)")
+        if temporal_patch_size <= 1:
+            raise NotImplementedError("temporal_patch_size == 1 (VideoPatchEmbed) is not built")
+        assert (temporal_patch_size, patch_size) == (decoder_temporal_patch_size, decoder_patch_size), \
+            "unpatchify uses the ENCODER patch sizes (larp_tokenizer.py:447-449): encoder and decoder patch sizes must match"
+        assert encoder_hidden_size == decoder_hidden_size and encoder_num_heads == decoder_num_heads, \
+            "the fused engine is built for equal encoder/decoder width"
+
+        self.train_type = train_type
+        self.bottleneck_type = bottleneck_type
+        self.in_channels = in_channels
+        self.out_channels = in_channels
+        self.input_size = input_size
+        self.frame_num = frame_num
+        self.bottleneck_token_num = bottleneck_token_num
+        self.temporal_patch_size = temporal_patch_size
+        self.patch_size = patch_size
+        self.decoder_temporal_patch_size = decoder_temporal_patch_size
+        self.decoder_patch_size = decoder_patch_size
+        self.decoder_latent_len = bottleneck_token_num
+        self.encoder_hidden_size = encoder_hidden_size = int(encoder_hidden_size)
+        self.decoder_hidden_size = decoder_hidden_size = int(decoder_hidden_size)
+        self.encoder_num_heads = encoder_num_heads = int(encoder_num_heads)
+        self.decoder_num_heads = decoder_num_heads = int(decoder_num_heads)
+        self.latent_pe_scale_factor = latent_pe_scale_factor
+        self.query_init_std = query_init_std
+
+        self.x_embedder = PatchEmbed3D(input_size, frame_num, patch_size, temporal_patch_size, in_channels, encoder_hidden_size, bias=True)
+        self.token_h = token_h = self.token_w = int(self.x_embedder.num_spatial_patches ** 0.5)
+        self.token_t = token_t = self.x_embedder.num_temporal_patches
+        self.video_token_num = video_token_num = self.x_embedder.num_spatial_patches * token_t
+        assert input_size % decoder_patch_size == 0, "input_size must be divisible by decoder_patch_size"
+        self.decoder_token_t = frame_num // decoder_temporal_patch_size
+        self.decoder_token_h = self.decoder_token_w = input_size // decoder_patch_size
+        self.recon_video_token_num = recon_video_token_num = self.decoder_token_h ** 2 * self.decoder_token_t
+
+        self.learned_encoder_patch_pe = False
+        self.register_buffer("encoder_patch_pe", torch.zeros(1, video_token_num, encoder_hidden_size))
+        self.use_encoder_patch_token_type_embed = False
+        self.learned_encoder_latent_query_embed = True
+        self.encoder_query_gaussian_init = encoder_query_gaussian_init
+        self.encoder_latent_query_embed = nn.Parameter(torch.zeros(bottleneck_token_num, encoder_hidden_size), requires_grad=True)
+        self.use_encoder_latent_query_token_type_embed = False
+        self.learned_decoder_latent_pe = False
+        self.register_buffer("decoder_latent_pe", torch.zeros(1, self.decoder_latent_len, decoder_hidden_size))
+        self.use_decoder_latent_token_type_embed = False
+        self.learned_decoder_patch_query_embed = False
+        self.register_buffer("decoder_patch_query_embed", torch.zeros(1, recon_video_token_num, decoder_hidden_size))
+        self.use_decoder_patch_query_token_type_embed = use_decoder_patch_query_token_type_embed
+        if use_decoder_patch_query_token_type_embed:
+            self.decoder_patch_query_token_type_embed = nn.Parameter(torch.zeros(1, 1, decoder_hidden_size), requires_grad=True)
+
+        def _name(n):
+            return transformer_name if n is None or str(n).lower() in ("none", "no", "null", "") else n
+        enc_args = {"name": _name(encoder_name), "args": {"dim": encoder_hidden_size, "depth": encoder_depth, "n_head": encoder_num_heads,
+                                                          "head_dim": encoder_hidden_size // encoder_num_heads}}
+        dec_args = {"name": _name(decoder_name), "args": {"dim": decoder_hidden_size, "depth": decoder_depth, "n_head": decoder_num_heads,
+                                                          "head_dim": decoder_hidden_size // decoder_num_heads}}
+        self.encoder = registry.make(enc_args)
+        self.decoder = registry.make(dec_args)
+
+        self.bottleneck_dim = bottleneck["args"]["bottleneck_dim"]
+        self.bottleneck = registry.make(bottleneck, args={"token_nums": self.bottleneck_token_num, "input_dim": encoder_hidden_size,
+                                                          "output_dim": decoder_hidden_size})
+        self.codebook_size = bottleneck["args"]["regularizer"]["args"]["codebook_size"]
+        self.final_layer = OutputLayer(decoder_hidden_size, decoder_temporal_patch_size, decoder_patch_size, self.out_channels)
+        self.prior_model = None  # the reference never builds one (larp_tokenizer.py:239-241); the trainer reads the attribute
+        self.initialize_weights()
+        self._engine = _engine.TokenizerEngine(self)
+
+    # ------------------------------------------------------------------------------- init
+    def initialize_weights(self):
+        """larp_tokenizer.py:249-328: xavier-uniform Linears (and the conv viewed 2-D), zero biases, sin-cos
+        buffers, N(0, std^2) latent queries / token-type embed, ZERO output layer."""
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        D = self.encoder_hidden_size
+        pe = get_3d_sincos_pos_embed(D, self.token_h, self.token_t)
+        self.encoder_patch_pe.data.copy_(torch.from_numpy(pe).float().reshape_as(self.encoder_patch_pe))
+        if self.encoder_query_gaussian_init:
+            q = torch.randn(self.bottleneck_token_num, D) * self.query_init_std
+        else:
+            q = torch.from_numpy(get_1d_sincos_pos_embed_from_grid(D, np.arange(self.bottleneck_token_num))).float()
+        self.encoder_latent_query_embed.data.copy_(q)
+        lp = get_1d_sincos_pos_embed_from_grid(self.decoder_hidden_size, np.arange(self.decoder_latent_len), self.latent_pe_scale_factor)
+        self.decoder_latent_pe.data.copy_(torch.from_numpy(lp).float().reshape_as(self.decoder_latent_pe))
+        dq = get_3d_sincos_pos_embed(self.decoder_hidden_size, self.decoder_token_h, self.decoder_token_t)
+        self.decoder_patch_query_embed.data.copy_(torch.from_numpy(dq).float().reshape_as(self.decoder_patch_query_embed))
+        if self.use_decoder_patch_query_token_type_embed:
+            self.decoder_patch_query_token_type_embed.data.copy_(torch.randn(1, 1, self.decoder_hidden_size) * 0.02)
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.constant_(self.x_embedder.proj.bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    # ------------------------------------------------------------------------------- small API
+    def get_last_layer(self):
+        return self.final_layer.linear.weight
+
+    def set_vq_eval_deterministic(self, deterministic=True):
+        self.bottleneck.regularizer.set_eval_deterministic(deterministic)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def decoder_parameters(self):
+        return itertools.chain(self.decoder.parameters(), self.final_layer.parameters())
+
+    def decoder_requires_grad_(self, requires_grad):
+        for p in self.decoder_parameters():
+            p.requires_grad_(requires_grad)
+
+    def others_parameters(self):
+        dec = set(self.decoder_parameters())
+        return (p for p in self.parameters() if p not in dec)
+
+    def others_requires_grad_(self, requires_grad):
+        for p in self.others_parameters():
+            p.requires_grad_(requires_grad)
+
+    @classmethod
+    def from_checkpoint(cls, ckpt, load_state_dict=True, version="sd"):
+        """larp_tokenizer.py:376-398.  Files are read with weights_only=True (nothing is executed from them)."""
+        if isinstance(ckpt, str):
+            assert os.path.exists(ckpt), f"checkpoint {ckpt} does not exist"
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+        else:
+            assert isinstance(ckpt, dict), "checkpoint must be a dict or a path to a checkpoint"
+        model = cls(**ckpt["model"]["args"])
+        if load_state_dict:
+            if version == "sd":
+                sd = ckpt["model"]["sd"]
+            elif version.startswith("ema"):
+                assert "_" in version, "ema version must be in the format 'ema_{alpha}'"
+                sd = ckpt["model"]["ema_sd"][float(version.split("_")[1])]
+            else:
+                raise ValueError(f"Unknown version: {version}")
+            model.load_state_dict(sd, strict=True)
+        return model
+
+    # ------------------------------------------------------------------------------- hot path
+    def _bottleneck_dict(self, o):
+        zero = torch.zeros((), device=o["losses"].device)
+        return {
+            "bottleneck_rep": o["indices"], "projected_z": o["projected_z"],
+            "input_norm_first": o["input_norms"][0], "input_norm_last": o["input_norms"][1],
+            "unregularized_z": o["unregularized_z"], "emb": o["emb"], "regularized_z": o["regularized_z"],
+            "loss_q": o["losses"][0], "loss_commit": o["losses"][1], "loss_codebook": o["losses"][2],
+            "loss_entropy": zero, "per_sample_entropy": zero, "codebook_entropy": zero,
+        }
+
+    def forward(self, data, **kwargs):
+        """larp_tokenizer.py:489-496: {'pred_frames', 'encoded', **bottleneck outputs}.  Differentiable outputs:
+        pred_frames, loss_q, loss_commit, loss_codebook (what the trainer back-propagates,
+        trainers/larp_tokenizer_trainer.py:294-333,372)."""
+        pred, losses, encoded, idx, pz, uz, rz, emb, norms = _engine.apply(self._engine, data)
+        o = {"indices": idx, "projected_z": pz, "input_norms": norms, "unregularized_z": uz, "emb": emb, "regularized_z": rz, "losses": losses}
+        return {"pred_frames": pred, "encoded": encoded, **self._bottleneck_dict(o)}
+
+    @torch.no_grad()
+    def encode(self, x):
+        """larp_tokenizer.py:400-428 (vq branch), forward only."""
+        _, _, o = _engine.run_encode(self._engine, x)
+        return {"encoded": o["encoded"], **self._bottleneck_dict(o)}
+
+    @torch.no_grad()
+    def encode_eval(self, x):
+        """larp_tokenizer.py:430-439: may encode fewer frames (PE prefix), returns num_x_tokens."""
+        out = self.encode(x)
+        _, _, T, S, _ = x.shape
+        out["num_x_tokens"] = (T // self.temporal_patch_size) * (S // self.patch_size) ** 2
+        return out
+
+    @torch.no_grad()
+    def decode(self, z, num_x_tokens=None):
+        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video."""
+        if not z.is_cuda:
+            raise hip.HipError("LARPTokenizer.decode: input is on the CPU; no CPU fallback")
+        eng = self._engine
+        B = z.shape[0]
+        per_frame = self.decoder_token_h ** 2
+        nv = self.recon_video_token_num if num_x_tokens is None else int(num_x_tokens)
+        assert nv % per_frame == 0
+        T = (nv // per_frame) * self.temporal_patch_size
+        st = eng.state_for(B, T, self.input_size, z.device)
+        ps = eng.param_struct()
+        eng.ensure_packed(st, ps)
+        st.fwd_id += 1
+        return _engine.run_decode(eng, st, ps, z.contiguous().float(), B, T, self.input_size)
+
+    def decode_eval(self, z, num_x_tokens=None):
+        return self.decode(z, num_x_tokens)
+
+    @torch.no_grad()
+    def decode_from_bottleneck(self, bottleneck_rep):
+        """larp_tokenizer.py:484-487: indices (b, Nq) -> bottleneck.decode -> decode."""
+        import ctypes
+        if not bottleneck_rep.is_cuda:
+            raise hip.HipError("LARPTokenizer.decode_from_bottleneck: input is on the CPU; no CPU fallback")
+        eng = self._engine
+        B = bottleneck_rep.shape[0]
+        st = eng.state_for(B, self.frame_num, self.input_size, bottleneck_rep.device)
+        ps = eng.param_struct()
+        eng.ensure_packed(st, ps)
+        ids = bottleneck_rep.contiguous().to(torch.int64)
+        enc = torch.empty(B, self.bottleneck_token_num, self.decoder_hidden_size, device=ids.device, dtype=torch.float32)
+        hip.check(hip.lib().vt_tokenizer_codes_to_encoded(st.handle, ctypes.byref(ps.struct), hip.ptr(ids), hip.ptr(st.ws), hip.ptr(enc), hip.stream()),
+                  "vt_tokenizer_codes_to_encoded")
+        return self.decode(enc)
