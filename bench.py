@@ -8,7 +8,7 @@ bs=8 per GPU, bf16 MFMA with fp32 accumulate, `LARPTokenizer(bottleneck_type='vq
 
 A "step" = model(data) -> L1 reconstruction loss + 0.1*loss_q (the model-side part of
 trainers/larp_tokenizer_trainer.py:_iter_step; LPIPS/GAN are out of scope) -> backward through the HIP
-engine (-> bucketed RCCL gradient all-reduce) -> fused Adam-free? No: `--optimizer` adds torch Adam.
+engine (-> bucketed RCCL gradient all-reduce); `--optimizer` additionally runs torch.optim.Adam in the step.
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -86,7 +86,12 @@ def cpu_baseline(c, sd_seed=7):
     same workload, forward + backward, stochastic=False index path (multinomial is not the cost)."""
     from oracle import inputs as gen
     from oracle import larp_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = min(ncpu, 16)  # the GPU box grants a 16-core share per GPU; more threads only oversubscribe it
+    torch.set_num_threads(ncpu)
     sd = O.init_state_dict(c, seed=sd_seed)
     p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("_pe") and k != "decoder_patch_query_embed") for k, v in sd.items()}
     x = torch.from_numpy(gen.video_clips(1, c["frame_num"], c["input_size"], 3))

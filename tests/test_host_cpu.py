@@ -1,0 +1,189 @@
+"""CPU tests of the host side: registry semantics, state-dict/ckpt layout, PE buffers, config surface,
+C-ABI export list, loud failure without a GPU.  No compute kernels are called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import video_tokenizer_amd as vt
+from oracle import larp_oracle as O
+from tests.test_model_gpu import spec_from_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_make_filters_kwargs_and_loads_sd():
+    @vt.register("_probe")
+    class Probe(torch.nn.Module):
+        def __init__(self, a, b=2):
+            super().__init__()
+            self.a, self.b = a, b
+            self.w = torch.nn.Parameter(torch.zeros(3))
+    m = vt.make({"name": "_probe", "args": {"a": 1, "junk": 5}}, args={"b": 7})
+    assert (m.a, m.b) == (1, 7)
+    m2 = vt.make({"name": "_probe", "args": {"a": 1}, "sd": {"w": torch.ones(3)}}, load_sd=True)
+    assert torch.equal(m2.w.data, torch.ones(3))
+    assert {"larp_tokenizer", "transformer_encoder_parallel", "bottleneck", "vq"} <= set(vt.models)
+
+
+def test_module_layout_matches_reference_state_dict():
+    cfg = O.make_cfg("tiny")
+    m = vt.make(spec_from_cfg(cfg, stochastic=True))
+    sd, ref = m.state_dict(), O.init_state_dict(cfg)
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    m.load_state_dict(ref, strict=True)
+    # buffers are in the checkpoint: they must equal the reference-pinned sin-cos tables bit for bit
+    assert torch.equal(vt.make(spec_from_cfg(cfg)).encoder_patch_pe, ref["encoder_patch_pe"])
+    assert torch.equal(vt.make(spec_from_cfg(cfg)).decoder_latent_pe, ref["decoder_latent_pe"])
+    assert torch.equal(vt.make(spec_from_cfg(cfg)).decoder_patch_query_embed, ref["decoder_patch_query_embed"])
+    assert m.prior_model is None and m.output_format == "bcthw" and m.codebook_size == cfg["codebook_size"]
+    assert m.bottleneck_token_num == cfg["bottleneck_token_num"] and m.x_embedder.strict_vid_size is True
+    # zero-initialised head like the reference (larp_tokenizer.py:327-328)
+    fresh = vt.make(spec_from_cfg(cfg))
+    assert fresh.final_layer.linear.weight.abs().sum() == 0 and fresh.final_layer.norm_final.eps == 1e-6
+    assert fresh.encoder.blocks[0].norm1.eps == 1e-5
+
+
+def test_base_config_parameter_count():
+    """config B: 173.4 M parameters (694 MB of fp32 gradients)."""
+    m = vt.make(spec_from_cfg(O.make_cfg("B"), stochastic=True))
+    n = sum(p.numel() for p in m.parameters())
+    assert abs(n - 173.4e6) < 0.2e6, n
+
+
+def test_from_checkpoint_roundtrip_and_extra_keys(tmp_path):
+    cfg = O.make_cfg("tiny")
+    spec = spec_from_cfg(cfg)
+    m = vt.make(spec)
+    m.load_state_dict(O.init_state_dict(cfg), strict=True)
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"model": {"name": "larp_tokenizer", "args": spec["args"], "sd": m.state_dict(), "ema_sd": {0.999: m.state_dict()}}, "epoch": 3}, path)
+    a = vt.LARPTokenizer.from_checkpoint(path)                       # yaml extras such as use_pe are accepted and ignored
+    b = vt.LARPTokenizer.from_checkpoint(path, version="ema_0.999")
+    for k, v in m.state_dict().items():
+        assert torch.equal(a.state_dict()[k], v) and torch.equal(b.state_dict()[k], v)
+    with pytest.raises(ValueError):
+        vt.LARPTokenizer.from_checkpoint(path, version="bogus")
+
+
+def test_unsupported_options_fail_loudly():
+    cfg = O.make_cfg("tiny")
+    s = spec_from_cfg(cfg)
+    s["args"]["bottleneck_type"] = "sq"
+    with pytest.raises(NotImplementedError):
+        vt.make(s)
+    s = spec_from_cfg(cfg)
+    s["args"]["learned_encoder_patch_pe"] = True
+    with pytest.raises(NotImplementedError):
+        vt.make(s)
+
+
+def test_cpu_tensors_are_refused():
+    cfg = O.make_cfg("tiny")
+    m = vt.make(spec_from_cfg(cfg))
+    x = torch.zeros(1, 3, cfg["frame_num"], cfg["input_size"], cfg["input_size"])
+    for call in (lambda: m(x), lambda: m.encode(x), lambda: m.decode(torch.zeros(1, cfg["bottleneck_token_num"], 768)),
+                 lambda: m.decode_from_bottleneck(torch.zeros(1, cfg["bottleneck_token_num"], dtype=torch.long))):
+        with pytest.raises(vt.hip.HipError):
+            call()
+    with pytest.raises(RuntimeError):
+        m.encoder(x, x)  # sub-modules have no standalone (or CPU) path
+
+
+def test_vq_index_mode_follows_reference_flags():
+    from video_tokenizer_amd.bottleneck import SimpleVectorQuantizer as VQ
+    assert VQ(24, 16, l2_normalized=True, stochastic=False).index_mode() == 0
+    v = VQ(24, 16, l2_normalized=True, stochastic=True, stochastic_temperature=0.03)
+    assert v.index_mode() == 2 and abs(v.inv_tau() - 1 / 0.03) < 1e-9
+    v.eval()
+    assert v.index_mode() == 2          # eval without --det still samples (bottleneck.py:277-280)
+    v.set_eval_deterministic(True)
+    assert v.index_mode() == 1
+    v.train()
+    assert v.index_mode() == 2
+
+
+YAML = """
+trainer: larp_tokenizer_trainer
+train_dataset:
+  name: video_dataset
+  args: {csv_file: $csv_file$, frame_num: $frame_num$, input_size: $input_size$}
+model:
+  name: some_other_model
+  args:
+    bottleneck:
+      name: bottleneck
+      args: {bottleneck_dim: 24, norm: 'none', regularizer: {name: vq, args: {codebook_size: 512, l2_normalized: true, stochastic: true, stochastic_temperature: 0.03}}}
+    prior_model: {name: none}
+    bottleneck_token_num: 56
+    bottleneck_type: 'sq'
+    input_size: 256
+    frame_num: $frame_num$
+    temporal_patch_size: 2
+    patch_size: 16
+    decoder_temporal_patch_size: 2
+    decoder_patch_size: 16
+    encoder_depth: 12
+    decoder_depth: 12
+    use_decoder_patch_query_token_type_embed: true
+    use_pe: 'yes'
+optimizer: {args: {betas: [0.5, 0.9]}}
+"""
+
+
+def test_yaml_surface_vars_and_opts():
+    from video_tokenizer_amd.config import load_cfg
+    args = {"csv_file": "null128", "frame_num": 4, "input_size": 32}
+    cfg = load_cfg(YAML, args, ["model.name", "larp_tokenizer", "model.args.bottleneck_type", "vq", "model.args.input_size", "32",
+                                "model.args.encoder_depth", "2", "model.args.decoder_depth", "2",
+                                "model.args.use_decoder_patch_query_token_type_embed", "false", "optimizer.args.betas", "0.9_0.95"])
+    assert cfg.train_dataset.args.csv_file == "null128" and cfg.model.args.frame_num == 4
+    assert cfg.model.args.input_size == 32 and isinstance(cfg.model.args.input_size, int)
+    assert cfg.model.args.use_decoder_patch_query_token_type_embed is False
+    assert cfg.optimizer.args.betas == [0.9, 0.95]
+    m = vt.make(cfg.model)
+    assert m.encoder.depth == 2 and m.video_token_num == 8 and not m.use_decoder_patch_query_token_type_embed
+    with pytest.raises(KeyError):
+        load_cfg(YAML, args, ["model.args.not_a_key", "1"])
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = vt.hip.lib()  # loads libvt_hip.so and binds argtypes for every signature
+    bound = set(vt.hip.SIGNATURES) | set(vt.hip.ENGINE_SIGNATURES)
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.vt_abi_version() == 1
+    # argument validation runs on the host before any launch: bad arguments give a code and a message, no GPU needed
+    p = vt.hip.GemmNT()
+    assert lib.vt_gemm_nt(ctypes.byref(p), None) == -1
+    buf = ctypes.create_string_buffer(256)
+    lib.vt_last_error(buf, 256)
+    assert b"vt_gemm_nt" in buf.value
+    h = ctypes.c_void_p()
+    cfg = vt.hip.TokenizerConfig()
+    assert lib.vt_tokenizer_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+
+
+def test_engine_plan_sizes_host_only():
+    """vt_tokenizer_create / workspace_bytes are pure host planning: config B at 8 clips/GPU fits easily in 288 GB."""
+    lib = vt.hip.lib()
+    c = vt.hip.TokenizerConfig()
+    c.B, c.C, c.T, c.S, c.pt, c.p = 8, 3, 16, 128, 2, 16
+    c.D, c.H, c.depth_enc, c.depth_dec, c.Nq, c.d, c.K = 768, 12, 12, 12, 1024, 24, 8192
+    c.vq_mode, c.l2_normalized, c.inv_tau, c.beta, c.codebook_w = 2, 1, 33.3, 0.25, 1.0
+    h = ctypes.c_void_p()
+    assert lib.vt_tokenizer_create(ctypes.byref(c), ctypes.byref(h)) == 0
+    nbytes = lib.vt_tokenizer_workspace_bytes(h)
+    assert 8e9 < nbytes < 20e9, nbytes
+    assert lib.vt_tokenizer_num_backward_stages(h) == 27
+    lib.vt_tokenizer_destroy(h)

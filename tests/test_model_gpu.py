@@ -104,11 +104,15 @@ def test_state_dict_layout_and_eval_paths():
     assert rel(a["pred_frames"].cpu(), ref["pred_frames"]) < 2e-2
     # training default = stochastic sampling: indices differ from argmax for some tokens, output stays finite
     model.train()
+    s0 = model(x)
+    # at tau = 0.03 this tiny model's latents all sit on one code; a flat temperature makes draws visibly random
+    model.bottleneck.regularizer.set_stochastic_temperature(1.0)
     s1 = model(x)
     s2 = model(x)
     torch.cuda.synchronize()
-    assert torch.isfinite(s1["pred_frames"]).all()
+    assert torch.isfinite(s0["pred_frames"]).all() and torch.isfinite(s1["pred_frames"]).all()
     assert (s1["bottleneck_rep"] != s2["bottleneck_rep"]).any()
+    assert len(torch.unique(s1["bottleneck_rep"])) > 16
 
 
 def test_cpu_input_fails_loudly():

@@ -30,8 +30,16 @@ def _rand(shape, seed, std=1.0):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=[1, 2], ids=["tile128", "tile192"], autouse=False)
+def gemm_variant(request, hip):
+    """run a GEMM test once per tile generation (vt_set_gemm_variant), then restore auto dispatch"""
+    hip.check(hip.lib().vt_set_gemm_variant(request.param), "vt_set_gemm_variant")
+    yield request.param
+    hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (256, 24, 768), (130, 1000, 192)])
-def test_gemm_nt_bf16_and_bias(hip, M, N, K):
+def test_gemm_nt_bf16_and_bias(hip, M, N, K, gemm_variant):
     A, B = bf(_rand((M, K), 1)), bf(_rand((N, K), 2))
     bias = torch.from_numpy(_rand((N,), 3))
     ref = A.float() @ B.float().t() + bias
@@ -40,7 +48,7 @@ def test_gemm_nt_bf16_and_bias(hip, M, N, K):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.to(torch.bfloat16).float().numpy(), rtol=2e-2, atol=2e-2)
 
 
-def test_gemm_nt_exact_integers_asymmetric(hip):
+def test_gemm_nt_exact_integers_asymmetric(hip, gemm_variant):
     """A = I (padded), asymmetric integer B: catches a transposed or permuted C write exactly."""
     M, N, K = 128, 256, 128
     A = torch.zeros(M, K)
@@ -52,7 +60,7 @@ def test_gemm_nt_exact_integers_asymmetric(hip):
     assert torch.equal(out.cpu(), ref)
 
 
-def test_gemm_nt_gelu_and_dgelu(hip):
+def test_gemm_nt_gelu_and_dgelu(hip, gemm_variant):
     M, N, K = 200, 320, 128
     A, B = bf(_rand((M, K), 4, 0.5)), bf(_rand((N, K), 5, 0.5))
     bias = torch.from_numpy(_rand((N,), 6, 0.1))
@@ -71,7 +79,7 @@ def test_gemm_nt_gelu_and_dgelu(hip):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2e-2, atol=3e-2)
 
 
-def test_gemm_nt_f32_residual_rowmod_rowmap(hip):
+def test_gemm_nt_f32_residual_rowmod_rowmap(hip, gemm_variant):
     Bt, n, seq, off, N, K = 3, 40, 100, 60, 256, 128
     M = Bt * n
     A, B = bf(_rand((M, K), 8)), bf(_rand((N, K), 9))
@@ -94,7 +102,7 @@ def test_gemm_nt_f32_residual_rowmod_rowmap(hip):
     np.testing.assert_allclose(out2.float().cpu().numpy()[off:off + n], ref.to(torch.bfloat16).float().numpy()[off:off + n], rtol=1e-2, atol=3e-2)
 
 
-def test_gemm_tn_grouped(hip):
+def test_gemm_tn_grouped(hip, gemm_variant):
     M = 256
     dY1, X1 = bf(_rand((M, 192), 13)), bf(_rand((M, 136), 14))
     dY2, X2 = bf(_rand((M, 64), 15)), bf(_rand((M, 320), 16))
@@ -112,7 +120,32 @@ def test_gemm_tn_grouped(hip):
     assert torch.all(got2[24:] == -5.0)
 
 
-def test_gemm_tn_exact_integers(hip):
+@pytest.mark.parametrize("M,N,K", [(384, 384, 512), (200, 400, 320)])
+def test_gemm_nt_exact_integers_multi_ktile(hip, gemm_variant, M, N, K):
+    """small-integer operands: every product and partial sum is exact in fp32, so the result must be bit-exact
+    whatever the tile size, pipeline depth or LDS ring position (catches stale-buffer races)."""
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    for _ in range(3):
+        out = hip.gemm_nt(A.to(torch.bfloat16).cuda(), B.to(torch.bfloat16).cuda(), hip.EPI_F32)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), A @ B.t())
+
+
+@pytest.mark.parametrize("M,P,Q", [(512, 384, 192), (320, 200, 392)])
+def test_gemm_tn_exact_integers_multi_ktile(hip, gemm_variant, M, P, Q):
+    g = torch.Generator().manual_seed(4)
+    dY = torch.randint(-3, 4, (M, P), generator=g).float()
+    X = torch.randint(-3, 4, (M, Q), generator=g).float()
+    for _ in range(3):
+        out = torch.zeros(P, Q).cuda()
+        hip.gemm_tn_grouped([dict(A=dY.to(torch.bfloat16).cuda(), B=X.to(torch.bfloat16).cuda(), out=out)])
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), dY.t() @ X)
+
+
+def test_gemm_tn_exact_integers(hip, gemm_variant):
     M, P, Q = 128, 128, 128
     dY = ((torch.arange(M).reshape(M, 1) * 5 + torch.arange(P).reshape(1, P) * 3) % 9).float()
     X = ((torch.arange(M).reshape(M, 1) + torch.arange(Q).reshape(1, Q) * 7) % 5).float()

@@ -1,0 +1,74 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  The reducer is the same code that runs over RCCL."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import video_tokenizer_amd as vt
+        from oracle import larp_oracle as O
+        from tests.test_model_gpu import spec_from_cfg
+        from video_tokenizer_amd.engine import _flat_order
+        from video_tokenizer_amd.parallel import DataParallelTokenizer, GradReducer
+        torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's weights
+        m = vt.make(spec_from_cfg(O.make_cfg("tiny"), stochastic=True))
+        dp = DataParallelTokenizer(m, bucket_bytes=4 << 20)
+        chk = torch.cat([p.detach().reshape(-1)[:4] for p in m.parameters()])
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        # feed the reducer the stage slices exactly as the engine reports them
+        eng = m._engine
+        eng.ensure_flat_grad(torch.device("cpu"))
+        nst = max(eng.segments) + 1
+        assert sorted(eng.segments) == list(range(nst))
+        assert eng.segments[0][0] == 0 and eng.segments[nst - 1][1] == eng.flat_grad.numel()
+        assert all(eng.segments[s][1] == eng.segments[s + 1][0] for s in range(nst - 1))
+        g = torch.Generator().manual_seed(5 + rank)
+        local = torch.randn(eng.flat_grad.numel(), generator=g)
+        eng.flat_grad.copy_(local)
+        red = eng.reducer
+        assert isinstance(red, GradReducer)
+        for s in range(nst):
+            red.segment_ready(eng.flat_grad, *eng.segments[s])
+        red.finish()
+        others = [torch.randn(eng.flat_grad.numel(), generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+        mean = sum(others) / world
+        ok_mean = torch.allclose(eng.flat_grad, mean, atol=1e-6)
+        covered = red.launched[0][0] == 0 and red.launched[-1][1] == eng.flat_grad.numel() and \
+            all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:]))
+        q.put((rank, same, ok_mean, covered, len(red.launched), len(_flat_order(m))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, ok_mean, covered, nb, nparams in res:
+        assert same, "parameters were not broadcast from rank 0"
+        assert ok_mean, "gradient mean over ranks is wrong"
+        assert covered, "buckets do not tile the flat gradient buffer"
+        assert nb >= 2 and nparams == 57

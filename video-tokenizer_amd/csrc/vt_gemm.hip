@@ -14,6 +14,7 @@
 // The MFMA is issued as D' = B_frag x A_frag so that one lane ends up with FOUR CONSECUTIVE OUTPUT
 // COLUMNS of one output row (16 B of fp32 / 8 B of bf16 per store) instead of four rows.
 #include "vt_common.h"
+#include "vt_gemm_epilogue.h"
 
 namespace {
 
@@ -107,84 +108,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wr * 64 + i * 16 + fr;
         if (m >= p.M) continue;
-        const int64_t orow = (EPI == VT_EPI_F32) ? omap(m) : (int64_t)m;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + fq * 4;
             if (n >= p.N) continue;
-            const bool full = (n + 3 < p.N);
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) v[r] += p.bias[n + r];
-            }
-            if constexpr (EPI == VT_EPI_BF16) {
-                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + n;
-                if (full) {
-                    *(bf16x4*)o = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = f2bf(v[r]);
-                }
-            } else if constexpr (EPI == VT_EPI_BF16_GELU) {
-                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + n;
-                bf16_t* o2 = (bf16_t*)p.out2 + orow * p.ldo2 + n;
-                bf16_t u[4], gl[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    u[r] = f2bf(v[r]);
-                    gl[r] = f2bf(gelu_erf(bf2f(u[r])));  // GELU of the bf16-rounded pre-activation (autocast order)
-                }
-                if (full) {
-                    *(bf16x4*)o = (bf16x4){u[0], u[1], u[2], u[3]};
-                    *(bf16x4*)o2 = (bf16x4){gl[0], gl[1], gl[2], gl[3]};
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) { o[r] = u[r]; o2[r] = gl[r]; }
-                }
-            } else if constexpr (EPI == VT_EPI_BF16_DGELU) {
-                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + n;
-                const bf16_t* ux = (const bf16_t*)p.aux + (int64_t)m * p.ldaux + n;
-                if (full) {
-                    const bf16x4 uu = *(const bf16x4*)ux;
-                    *(bf16x4*)o = (bf16x4){f2bf(v[0] * gelu_erf_grad(bf2f(uu[0]))), f2bf(v[1] * gelu_erf_grad(bf2f(uu[1]))),
-                                           f2bf(v[2] * gelu_erf_grad(bf2f(uu[2]))), f2bf(v[3] * gelu_erf_grad(bf2f(uu[3])))};
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = f2bf(v[r] * gelu_erf_grad(bf2f(ux[r])));
-                }
-            } else {  // VT_EPI_F32
-                if (p.round_bf16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = round_bf16(v[r]);
-                }
-                float* o = (float*)p.out + orow * p.ldo + n;
-                if (p.residual) {
-                    const float* rs = p.residual + orow * p.ldr + n;
-                    if (full) {
-                        const f32x4 rv = *(const f32x4*)rs;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                    } else {
-                        for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += rs[r];
-                    }
-                }
-                if (p.rowmod) {
-                    const float* rm = p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n;
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += rm[r];
-                }
-                if (full) {
-                    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
-                }
-                if (p.out2) {
-                    bf16_t* o2 = (bf16_t*)p.out2 + orow * p.ldo2 + n;
-                    if (full) {
-                        *(bf16x4*)o2 = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    } else {
-                        for (int r = 0; r < 4 && n + r < p.N; ++r) o2[r] = f2bf(v[r]);
-                    }
-                }
-            }
+            nt_epilogue<EPI>(p, omap, m, n, acc[i][j]);
         }
     }
 }
@@ -306,6 +234,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNArgs a) {
 
 }  // namespace
 
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s);
+int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s);
+int vt_gemm192_init();
+static int g_gemm_variant = 0;  // 0 auto, 1 force 128x128 tiles, 2 force 192x192 tiles
+
+// test/tuning hook: choose the tile generation used by vt_gemm_nt / vt_gemm_tn_grouped
+extern "C" int vt_set_gemm_variant(int32_t v) {
+    VT_CHECK_ARG(v >= 0 && v <= 2, "vt_set_gemm_variant: 0 auto, 1 = 128x128, 2 = 192x192");
+    g_gemm_variant = v;
+    return VT_OK;
+}
+
 extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
@@ -313,6 +253,10 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
     VT_CHECK_ARG(p.ldo % 4 == 0, "vt_gemm_nt: ldo must be a multiple of 4");
+    VT_CHECK_ARG(((uintptr_t)p.out & 15) == 0 && ((uintptr_t)p.bias & 15) == 0 && ((uintptr_t)p.out2 & 7) == 0 &&
+                 ((uintptr_t)p.residual & 15) == 0 && ((uintptr_t)p.rowmod & 15) == 0 && ((uintptr_t)p.aux & 7) == 0,
+                 "vt_gemm_nt: out/bias/residual/rowmod must be 16-byte aligned (out2/aux 8-byte)");
+    VT_CHECK_ARG(!p.rowmod || p.N % 4 == 0, "vt_gemm_nt: rowmod needs N %% 4 == 0");
     if (p.epi == VT_EPI_BF16_GELU) VT_CHECK_ARG(p.out2 && p.ldo2 % 4 == 0, "vt_gemm_nt: GELU epilogue needs out2");
     if (p.epi == VT_EPI_BF16_DGELU) VT_CHECK_ARG(p.aux && p.ldaux % 4 == 0, "vt_gemm_nt: DGELU epilogue needs aux");
     if (p.epi == VT_EPI_F32) {
@@ -321,6 +265,14 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
         VT_CHECK_ARG(!p.out2 || p.ldo2 % 4 == 0, "vt_gemm_nt: ldo2 must be a multiple of 4");
     } else {
         VT_CHECK_ARG(p.omap.grp == 0, "vt_gemm_nt: output row map only with VT_EPI_F32");
+    }
+    const bool big = g_gemm_variant == 2 || (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192);
+    if (big) {
+        int rc = vt_gemm192_init();
+        if (rc) return rc;
+        vt_gemm_nt192_launch(p, (hipStream_t)stream);
+        VT_CHECK_LAUNCH("vt_gemm_nt(192)");
+        return VT_OK;
     }
     NTArgs a;
     a.p = p;
@@ -345,6 +297,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     TNArgs a;
     a.n = n;
     a.tile_start[0] = 0;
+    bool big = g_gemm_variant != 1;
     for (int g = 0; g < n; ++g) {
         const vtGemmTN& p = ph[g];
         VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_tn_grouped[%d]: null operand", g);
@@ -356,6 +309,14 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
         a.p[g] = p;
         const int tp = (p.p_lim + BM - 1) / BM, tq = (p.q_lim + BN - 1) / BN;
         a.tile_start[g + 1] = a.tile_start[g] + tp * tq;
+        if (g_gemm_variant == 0 && (p.p_lim < 192 || p.q_lim < 192)) big = false;
+    }
+    if (big) {
+        int rc = vt_gemm192_init();
+        if (rc) return rc;
+        vt_gemm_tn192_launch(ph, n, (hipStream_t)stream);
+        VT_CHECK_LAUNCH("vt_gemm_tn_grouped(192)");
+        return VT_OK;
     }
     const dim3 grid(a.tile_start[n]), block(256);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 4 * TILE_B, (hipStream_t)stream, a);

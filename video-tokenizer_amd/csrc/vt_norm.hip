@@ -126,14 +126,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out[c] (+)= sum_s partial[s * stride + c]
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nslab, int64_t stride, int width,
-                                       float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+// outs[w][c] = sum_s partial[s * slab_stride + w * width + c]   for w < nout (<= 3)
+// workgroup = 32 columns x 8 slab lanes; fixed summation order => deterministic
+struct ReduceOuts {
+    float* o[3];
+};
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nslab, int64_t slab_stride, int width,
+                                                               ReduceOuts outs) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const int w = blockIdx.y;
     float s = 0.f;
-    for (int i = 0; i < nslab; ++i) s += partial[(int64_t)i * stride + c];
-    out[c] = s;
+    if (c < width) {
+        const float* p = partial + (int64_t)w * width + c;
+#pragma unroll 4
+        for (int i = ty; i < nslab; i += 8) s += p[(int64_t)i * slab_stride];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        outs.o[w][c] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,10 +303,9 @@ extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xm
     }
 #undef LN_BWD
     VT_CHECK_LAUNCH("vt_layernorm_bwd");
-    const int rb = (dim + 255) / 256;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, s, part, grid, (int64_t)3 * dim, dim, dgamma);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, s, part + dim, grid, (int64_t)3 * dim, dim, dbeta);
-    if (dxsum) hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, s, part + 2 * dim, grid, (int64_t)3 * dim, dim, dxsum);
+    ReduceOuts ro;
+    ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = dxsum;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 31) / 32, dxsum ? 3 : 2), dim3(256), 0, s, part, grid, (int64_t)3 * dim, dim, ro);
     VT_CHECK_LAUNCH("vt_layernorm_bwd/reduce");
     return VT_OK;
 }
@@ -310,7 +326,9 @@ extern "C" int vt_colsum(const void* src, int32_t src_is_bf16, int64_t ld, vtRow
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, ld, to_map(map), rows, width, rps, (float*)workspace);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, to_map(map), rows, width, rps, (float*)workspace);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, s, (const float*)workspace, slabs, (int64_t)width, width, out);
+    ReduceOuts ro;
+    ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32, 1), dim3(256), 0, s, (const float*)workspace, slabs, (int64_t)width, width, ro);
     VT_CHECK_LAUNCH("vt_colsum");
     return VT_OK;
 }

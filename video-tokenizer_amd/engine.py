@@ -307,7 +307,8 @@ class TokenizerFunction(torch.autograd.Function):
             elif saved is not None:
                 grads.append(engine.grad_views[name] - saved[engine.grad_offsets[name]:engine.grad_offsets[name] + named[name].numel()].view_as(named[name]))
             else:
-                grads.append(engine.grad_views[name])
+                # a FRESH view object (use_count 1) so AccumulateGrad adopts it instead of cloning 694 MB per step
+                grads.append(engine.grad_views[name].view(named[name].shape))
         return (None, None) + tuple(grads)
 
 

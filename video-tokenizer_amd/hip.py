@@ -41,6 +41,7 @@ SIGNATURES = {
     "vt_last_error": (c_i32, [ctypes.c_char_p, c_sz]),
     "vt_gemm_nt": (c_i32, [ctypes.POINTER(GemmNT), c_vp]),
     "vt_gemm_tn_grouped": (c_i32, [ctypes.POINTER(GemmTN), c_i32, c_vp]),
+    "vt_set_gemm_variant": (c_i32, [c_i32]),
     "vt_layernorm_fwd": (c_i32, [c_vp, RowMap, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32]),
     "vt_layernorm_bwd": (c_i32, [c_vp, c_vp, RowMap, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
