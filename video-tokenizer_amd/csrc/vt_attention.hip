@@ -97,10 +97,61 @@ __device__ __forceinline__ void store_own(const f32x16 (&acc)[2], float mul, bf1
         }
 }
 
+// one 64-key tile of the forward: S^T = K.Q^T, online softmax (log2 domain; max taken on the raw scores since
+// the scale is positive), O^T += V^T.P^T.  TAIL masks keys >= L (last tile of a ragged sequence only).
+template <bool TAIL>
+__device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& lsum,
+                                         int key0, int L, float c, int lane, int half) {
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc[kt], 0, 0, 0);
+    }
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (TAIL && (key0 + kt * 32 + reg_row(r, half) >= L)) sacc[kt][r] = -__builtin_inff();
+            mx = fmaxf(mx, sacc[kt][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx * c);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c, -mn));
+            sacc[kt][r] = p;
+            ps += p;
+        }
+    lsum = lsum * alpha + ps;
+    if (!__all(alpha == 1.0f)) {  // the running max moved for some query of this wave: rescale O
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 pf = pack8(sacc[kt], sp);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(vl, kt * 32, sp, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
                                                            int L, int H, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -127,60 +178,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     stage64(vb, rs, 0, L, smem + TILE, tid, wave);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    // hot loop: full 64-key tiles only; a ragged last tile (L % 64 != 0) runs once, after the loop, so its masking
+    // code never shares registers with the steady state
+    const int nfull = (L & 63) ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
             stage64(kb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE, tid, wave);
             stage64(vb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
         const char* kl = smem + cur * 2 * TILE;
-        const char* vl = kl + TILE;
-        f32x16 sacc[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc[kt], 0, 0, 0);
-        }
-        const bool tail = (t == nt - 1) && (L & 63);
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = sacc[kt][r] * scale_log2e;
-                if (tail && (t * 64 + kt * 32 + reg_row(r, half) >= L)) x = -__builtin_inff();
-                sacc[kt][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[kt][r] - mn);
-                sacc[kt][r] = p;
-                ps += p;
-            }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 pf = pack8(sacc[kt], sp);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(vl, kt * 32, sp, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
-            }
+        fwd_tile<false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
         __syncthreads();
+    }
+    if (nfull < nt) {
+        const char* kl = smem + (nfull & 1) * 2 * TILE;
+        fwd_tile<true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane, half);
     }
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const int q = q0 + (lane & 31);
@@ -210,10 +223,39 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __
     delta[(b * H + h) * L + q] = s;
 }
 
+template <bool TAIL>
+__device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], f32x16 (&dq)[2],
+                                        float my_lse, float my_delta, int key0, int L, float c, int lane, int half) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        f32x16 sacc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(vl, kt * 32, s, lane), dof[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -my_lse));
+            if (TAIL && (key0 + kt * 32 + reg_row(r, half) >= L)) p = 0.f;
+            sacc[r] = p * (dp[r] - my_delta);  // dS (unscaled)
+        }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 dsf = pack8(sacc, sp);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(kl, kt * 32, sp, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dQ: own rows = queries; streams K (row reads + transposed reads) and V (row reads)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               const float* __restrict__ lse2, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -245,42 +287,66 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     stage64(vb, rs, 0, L, smem + TILE, tid, wave);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    const int nfull = (L & 63) ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
             stage64(kb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE, tid, wave);
             stage64(vb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
-        const bool tail = (t == nt - 1) && (L & 63);
         const char* kl = smem + cur * 2 * TILE;
-        const char* vl = kl + TILE;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            f32x16 sacc, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(vl, kt * 32, s, lane), dof[s], dp, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(sacc[r] * scale_log2e - my_lse);
-                if (tail && (t * 64 + kt * 32 + reg_row(r, half) >= L)) p = 0.f;
-                sacc[r] = p * (dp[r] - my_delta);  // dS (unscaled)
-            }
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 dsf = pack8(sacc, sp);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(kl, kt * 32, sp, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
-            }
-        }
+        dq_tile<false>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, t * 64, L, scale_log2e, lane, half);
         __syncthreads();
     }
+    if (nfull < nt) {
+        const char* kl = smem + (nfull & 1) * 2 * TILE;
+        dq_tile<true>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, nfull * 64, L, scale_log2e, lane, half);
+    }
     store_own(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
+}
+
+// one 64-query tile of the dK/dV sweep.  LDS buffer: Q tile | dO tile | lse2[64] | delta[64]
+template <bool TAIL>
+__device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2], f32x16 (&dv)[2],
+                                         int q0, int L, float c, int lane, int half) {
+    const char* do_l = qt_l + TILE;
+    const float* lse_l = (const float*)(qt_l + 2 * TILE);
+    const float* del_l = lse_l + 64;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        f32x16 sacc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_l, qt * 32, s, lane), kf[s], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+        }
+        // this lane's 16 query rows are 4 runs of 4 consecutive rows: rows qt*32 + 8g + 4*half + 0..3
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 lse4 = *(const f32x4*)(lse_l + qt * 32 + 8 * g + 4 * half);
+            const f32x4 del4 = *(const f32x4*)(del_l + qt * 32 + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse4[e]));
+                if (TAIL && (q0 + qt * 32 + reg_row(r, half) >= L)) p = 0.f;
+                sacc[r] = p;
+                dp[r] = p * (dp[r] - del4[e]);
+            }
+        }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 pf = pack8(sacc, sp);
+            const bf16x8 dsf = pack8(dp, sp);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(do_l, qt * 32, sp, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_l, qt * 32, sp, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,45 +394,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     stage(0, 0);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    const int nfull = (L & 63) ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) stage(t + 1, cur ^ 1);
-        const bool tail = (t == nt - 1) && (L & 63);
-        const char* qt_l = smem + cur * BUF;
-        const char* do_l = qt_l + TILE;
-        const float* lse_l = (const float*)(qt_l + 2 * TILE);
-        const float* del_l = lse_l + 64;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            f32x16 sacc, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_l, qt * 32, s, lane), kf[s], sacc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qr = qt * 32 + reg_row(r, half);
-                float p = __builtin_amdgcn_exp2f(sacc[r] * scale_log2e - lse_l[qr]);
-                if (tail && (t * 64 + qr >= L)) p = 0.f;
-                sacc[r] = p;
-                dp[r] = p * (dp[r] - del_l[qr]);
-            }
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 pf = pack8(sacc, sp);
-                const bf16x8 dsf = pack8(dp, sp);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(do_l, qt * 32, sp, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_l, qt * 32, sp, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
-                }
-            }
-        }
+        dkv_tile<false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
         __syncthreads();
     }
+    if (nfull < nt) dkv_tile<true>(smem + (nfull & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
     bf16_t* dkb = dqkv + (int64_t)b * L * rs + (int64_t)h * HD + (int64_t)H * HD;
     store_own(dk, scale, dkb, rs, key, key < L, half);
     store_own(dv, 1.0f, dkb + (int64_t)H * HD, rs, key, key < L, half);

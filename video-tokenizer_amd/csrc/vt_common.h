@@ -49,6 +49,24 @@ __device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const VT_GLB void*)gsrc, (VT_LDS void*)lds_wave_base, 4, 0, 0);
 }
 
+// The same 16-byte LDS-DMA issued through inline asm: hipcc then does not know an LDS-DMA is in flight and keeps
+// emitting COUNTED lgkmcnt waits for ds_reads (with the builtin in flight it degrades every LDS wait to
+// lgkmcnt(0)).  The caller must order the DMA itself: s_waitcnt vmcnt(N) + barrier before any ds_read of the data.
+// lds_byte_addr must be wave-uniform (SGPR); M0 is saved/restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(VT_LDS const char*)p; }
+
 // transposed LDS read: per 16-lane group a 4-row x 16-col block of 16-bit elements; lane i of the
 // group receives column i (4 rows).  addr = this lane's 8-byte piece (row q = (i>>2), cols 4*(i&3)..).
 __device__ __forceinline__ bf16x4 lds_read_tr16(const void* lds_addr) {
@@ -64,11 +82,30 @@ __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
 __device__ __forceinline__ float round_bf16(float x) { return (float)((bf16_t)x); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU (timm Mlp act_layer=nn.GELU) without the branchy library erff: Abramowitz-Stegun 7.1.26,
+// erfc(z) = (a1 t + .. + a5 t^5) e^{-z^2}, t = 1/(1 + p z), |error| <= 1.5e-7 on erf -- three orders below the bf16
+// rounding applied to every GELU output/gradient here.  cdf is formed without cancellation on the negative side,
+// and the same exp(-x^2/2) serves the pdf term of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2)
+    const float hq = 0.5f * p * t * e;                             // 0.5 * erfc(|x|/sqrt2)
+    cdf = x >= 0.f ? 1.0f - hq : hq;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -86,19 +86,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
         }
         const char* la = smem + cur * 2 * TILE_B;
         const char* lb = la + TILE_B;
+        bf16x8 af[2][4], bfv[2][4];  // all 16 fragment reads first, MFMAs behind counted lgkmcnt waits
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_nt(la, wr * 64 + i * 16 + fr, kk * 4 + fq);
+            for (int j = 0; j < 4; ++j) bfv[kk][j] = frag_nt(lb, wc * 64 + j * 16 + fr, kk * 4 + fq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfv[j] = frag_nt(lb, wc * 64 + j * 16 + fr, kk * 4 + fq);
+            for (int i = 0; i < 4; ++i) af[kk][i] = frag_nt(la, wr * 64 + i * 16 + fr, kk * 4 + fq);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
 
@@ -195,19 +199,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNArgs a) {
         }
         const char* la = smem + cur * 2 * TILE_B;
         const char* lb = la + TILE_B;
+        bf16x8 af[2][4], bfv[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_tn(la, wr * 64 + i * 16, kk * 32, lane);
+            for (int j = 0; j < 4; ++j) bfv[kk][j] = frag_tn(lb, wc * 64 + j * 16, kk * 32, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfv[j] = frag_tn(lb, wc * 64 + j * 16, kk * 32, lane);
+            for (int i = 0; i < 4; ++i) af[kk][i] = frag_tn(la, wr * 64 + i * 16, kk * 32, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
 
@@ -266,7 +274,13 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     } else {
         VT_CHECK_ARG(p.omap.grp == 0, "vt_gemm_nt: output row map only with VT_EPI_F32");
     }
-    const bool big = g_gemm_variant == 2 || (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192);
+    // auto dispatch (measured on MI355X, tools/gemm_bench.py): the 192x192 3-stage kernel wins when its tiles fit
+    // the 256 CUs in one wave (N = 768 at M = 12288) or when K is long enough to amortise its un-overlapped
+    // epilogue (1 workgroup/CU); short-K / wide-N shapes with heavy epilogues (fc1+GELU) stay on 128x128 tiles
+    // whose 2 workgroups per CU overlap one's epilogue with the other's main loop.
+    const int64_t tiles192 = (int64_t)((p.M + 191) / 192) * ((p.N + 191) / 192);
+    const bool big = g_gemm_variant == 2 ||
+                     (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192 && (tiles192 <= 256 || p.K >= 1536));
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
@@ -297,7 +311,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     TNArgs a;
     a.n = n;
     a.tile_start[0] = 0;
-    bool big = g_gemm_variant != 1;
+    bool big = g_gemm_variant == 2;  // auto: 128x128 tiles (432 tiles per transformer block fill the chip; 192 tiles of 192x192 would not)
     for (int g = 0; g < n; ++g) {
         const vtGemmTN& p = ph[g];
         VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_tn_grouped[%d]: null operand", g);
@@ -309,7 +323,6 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
         a.p[g] = p;
         const int tp = (p.p_lim + BM - 1) / BM, tq = (p.q_lim + BN - 1) / BN;
         a.tile_start[g + 1] = a.tile_start[g] + tp * tq;
-        if (g_gemm_variant == 0 && (p.p_lim < 192 || p.q_lim < 192)) big = false;
     }
     if (big) {
         int rc = vt_gemm192_init();

@@ -36,7 +36,7 @@ struct NT192Args {
     int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ void stage_nt192(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0, char* lds, int tid, int wave) {
+__device__ __forceinline__ void stage_nt192(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0, unsigned lds, int tid, int wave) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int slot = i * 512 + tid;
@@ -44,7 +44,7 @@ __device__ __forceinline__ void stage_nt192(const bf16_t* __restrict__ g, int64_
         const int lc = (slot & 7) ^ ((row >> 1) & 7);
         int gr = row0 + row;
         gr = gr < nrows ? gr : nrows - 1;
-        glds16(g + (int64_t)gr * ld + k0 + lc * 8, lds + (i * 512 + wave * 64) * 16);
+        glds16_asm(g + (int64_t)gr * ld + k0 + lc * 8, lds + (i * 512 + wave * 64) * 16);
     }
 }
 
@@ -74,11 +74,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
         for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = p.K / TK;
-    stage_nt192(A, p.lda, m0, p.M, 0, smem, tid, wave);
-    stage_nt192(B, p.ldb, n0, p.N, 0, smem + OP_BYTES, tid, wave);
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    stage_nt192(A, p.lda, m0, p.M, 0, sbase, tid, wave);
+    stage_nt192(B, p.ldb, n0, p.N, 0, sbase + OP_BYTES, tid, wave);
     if (nt > 1) {
-        stage_nt192(A, p.lda, m0, p.M, TK, smem + STAGE_BYTES, tid, wave);
-        stage_nt192(B, p.ldb, n0, p.N, TK, smem + STAGE_BYTES + OP_BYTES, tid, wave);
+        stage_nt192(A, p.lda, m0, p.M, TK, sbase + STAGE_BYTES, tid, wave);
+        stage_nt192(B, p.ldb, n0, p.N, TK, sbase + STAGE_BYTES + OP_BYTES, tid, wave);
     }
     const int fr = lane & 15, fq = lane >> 4;
     int cur = 0;
@@ -87,24 +88,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
         raw_barrier();                                        // everyone's have; everyone is done reading tile t-1
         if (t + 2 < nt) {
             int nx = cur + 2; nx = nx >= NSTAGE ? nx - NSTAGE : nx;
-            stage_nt192(A, p.lda, m0, p.M, (t + 2) * TK, smem + nx * STAGE_BYTES, tid, wave);
-            stage_nt192(B, p.ldb, n0, p.N, (t + 2) * TK, smem + nx * STAGE_BYTES + OP_BYTES, tid, wave);
+            stage_nt192(A, p.lda, m0, p.M, (t + 2) * TK, sbase + nx * STAGE_BYTES, tid, wave);
+            stage_nt192(B, p.ldb, n0, p.N, (t + 2) * TK, sbase + nx * STAGE_BYTES + OP_BYTES, tid, wave);
         }
         const char* la = smem + cur * STAGE_BYTES;
         const char* lb = la + OP_BYTES;
+        // all 18 fragment reads of the K-tile are issued first (two register sets), in the order the MFMAs consume
+        // them; the MFMAs then start behind counted lgkmcnt waits while later reads are still in flight
+        // (the LGKM counter is 4 bits: keep <= 14 reads in flight so hipcc can emit counted waits)
+        bf16x8 af[2][6], bfv[2][3];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[6], bfv[3];
+        for (int j = 0; j < 3; ++j) bfv[0][j] = frag_nt192(lb, wn * 48 + j * 16 + fr, fq);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bfv[j] = frag_nt192(lb, wn * 48 + j * 16 + fr, kk * 4 + fq);
+        for (int i = 0; i < 6; ++i) af[0][i] = frag_nt192(la, wm * 96 + i * 16 + fr, fq);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) af[i] = frag_nt192(la, wm * 96 + i * 16 + fr, kk * 4 + fq);
+        for (int j = 0; j < 3; ++j) bfv[1][j] = frag_nt192(lb, wn * 48 + j * 16 + fr, 4 + fq);
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 2; ++i) af[1][i] = frag_nt192(la, wm * 96 + i * 16 + fr, 4 + fq);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[0][j], af[0][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2; i < 6; ++i) af[1][i] = frag_nt192(la, wm * 96 + i * 16 + fr, 4 + fq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[1][j], af[1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
@@ -132,7 +148,7 @@ struct TN192Args {
 // [64 m-rows][192 cols] bf16 image, 384-B rows = 24 chunks; physical chunk = (lc & ~7) | ((lc & 7) ^ f(row))
 __device__ __forceinline__ int swz_tn192(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
 
-__device__ __forceinline__ void stage_tn192(const bf16_t* __restrict__ g, int64_t ld, int m0, int c0, int ncols, char* lds, int tid, int wave) {
+__device__ __forceinline__ void stage_tn192(const bf16_t* __restrict__ g, int64_t ld, int m0, int c0, int ncols, unsigned lds, int tid, int wave) {
     const int maxchunk = (ncols >> 3) - 1;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -142,7 +158,7 @@ __device__ __forceinline__ void stage_tn192(const bf16_t* __restrict__ g, int64_
         const int lc = (pc & ~7) | ((pc & 7) ^ swz_tn192(row));
         int gc = (c0 >> 3) + lc;
         gc = gc < maxchunk ? gc : maxchunk;
-        glds16(g + (int64_t)(m0 + row) * ld + gc * 8, lds + (i * 512 + wave * 64) * 16);
+        glds16_asm(g + (int64_t)(m0 + row) * ld + gc * 8, lds + (i * 512 + wave * 64) * 16);
     }
 }
 
@@ -183,11 +199,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
         for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = p.M / TK;
-    stage_tn192(A, p.lda, 0, p0, p.P, smem, tid, wave);
-    stage_tn192(B, p.ldb, 0, q0, p.Q, smem + OP_BYTES, tid, wave);
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    stage_tn192(A, p.lda, 0, p0, p.P, sbase, tid, wave);
+    stage_tn192(B, p.ldb, 0, q0, p.Q, sbase + OP_BYTES, tid, wave);
     if (nt > 1) {
-        stage_tn192(A, p.lda, TK, p0, p.P, smem + STAGE_BYTES, tid, wave);
-        stage_tn192(B, p.ldb, TK, q0, p.Q, smem + STAGE_BYTES + OP_BYTES, tid, wave);
+        stage_tn192(A, p.lda, TK, p0, p.P, sbase + STAGE_BYTES, tid, wave);
+        stage_tn192(B, p.ldb, TK, q0, p.Q, sbase + STAGE_BYTES + OP_BYTES, tid, wave);
     }
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
@@ -195,24 +212,45 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
         raw_barrier();
         if (t + 2 < nt) {
             int nx = cur + 2; nx = nx >= NSTAGE ? nx - NSTAGE : nx;
-            stage_tn192(A, p.lda, (t + 2) * TK, p0, p.P, smem + nx * STAGE_BYTES, tid, wave);
-            stage_tn192(B, p.ldb, (t + 2) * TK, q0, p.Q, smem + nx * STAGE_BYTES + OP_BYTES, tid, wave);
+            stage_tn192(A, p.lda, (t + 2) * TK, p0, p.P, sbase + nx * STAGE_BYTES, tid, wave);
+            stage_tn192(B, p.ldb, (t + 2) * TK, q0, p.Q, sbase + nx * STAGE_BYTES + OP_BYTES, tid, wave);
         }
         const char* la = smem + cur * STAGE_BYTES;
         const char* lb = la + OP_BYTES;
+        // 36 transposed 8-byte reads per K-tile; at most 14 in flight (4-bit LGKM counter) ahead of the MFMAs
+        bf16x8 af[2][6], bfv[2][3];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[6], bfv[3];
+        for (int j = 0; j < 3; ++j) bfv[0][j] = frag_tn192(lb, wn * 48 + j * 16, 0, lane);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bfv[j] = frag_tn192(lb, wn * 48 + j * 16, kk * 32, lane);
+        for (int i = 0; i < 4; ++i) af[0][i] = frag_tn192(la, wm * 96 + i * 16, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) af[i] = frag_tn192(la, wm * 96 + i * 16, kk * 32, lane);
+        for (int i = 0; i < 4; ++i) {
+            if (i == 0) {
+                af[0][4] = frag_tn192(la, wm * 96 + 4 * 16, 0, lane);
+                af[0][5] = frag_tn192(la, wm * 96 + 5 * 16, 0, lane);
+            } else {
+                bfv[1][i - 1] = frag_tn192(lb, wn * 48 + (i - 1) * 16, 32, lane);
+            }
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[0][j], af[0][i], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 4; i < 6; ++i) {
+            af[1][2 * (i - 4)] = frag_tn192(la, wm * 96 + (2 * (i - 4)) * 16, 32, lane);
+            af[1][2 * (i - 4) + 1] = frag_tn192(la, wm * 96 + (2 * (i - 4) + 1) * 16, 32, lane);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[0][j], af[0][i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < 2) af[1][4 + i] = frag_tn192(la, wm * 96 + (4 + i) * 16, 32, lane);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[1][j], af[1][i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
