@@ -85,7 +85,7 @@ int vt_gemm_nt(const vtGemmNT* p_host, vtStream stream);
  * Q % 8 == 0; rows >= p_lim and cols >= q_lim of C are not stored; row_perm (optional,
  * int32[p_lim]) scatters row p of C to row row_perm[p].  At most VT_TN_MAX_GROUP problems.
  * ------------------------------------------------------------------------------------------ */
-#define VT_TN_MAX_GROUP 8
+#define VT_TN_MAX_GROUP 16
 typedef struct {
     const void* A; int64_t lda; /* bf16 [M,P]  (dY) */
     const void* B; int64_t ldb; /* bf16 [M,Q]  (X)  */
@@ -258,11 +258,15 @@ int vt_tokenizer_codes_to_encoded(vtTokenizer* tk, const vtTokenizerTensors* par
 /* backward of forward(); stages run in order head(0), decoder blocks (1..depth_dec, last block
  * first), bottleneck, encoder blocks, patch-embed; [stage_begin, stage_end) lets the caller
  * interleave gradient all-reduce buckets between stages.  d_pred [B,C,T,S,S] fp32;
- * gscal = device {dL/dloss_q, dL/dloss_commit, dL/dloss_codebook} or NULL. */
+ * gscal = device {dL/dloss_q, dL/dloss_commit, dL/dloss_codebook} or NULL.
+ * The weight-gradient GEMMs of up to 4 consecutive transformer blocks are deferred and issued as ONE
+ * grouped launch (768 tiles of 192x192 = 3 full rounds of the 256 CUs), so the gradients of a stage
+ * may become final a few stages later: *final_through (optional) receives the number of leading stages
+ * whose gradients are complete once the enqueued work has run. */
 int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* tk);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
-                          vtStream stream);
+                          int32_t* final_through, vtStream stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,44 @@ def test_cpu_input_fails_loudly():
     model, _ = build(cfg)
     with pytest.raises(vt.hip.HipError):
         model(torch.zeros(1, 3, cfg["frame_num"], cfg["input_size"], cfg["input_size"]))
+
+
+def test_data_parallel_wrapper_single_rank_rccl():
+    """The bucketed reducer on real HIP streams over RCCL (world size 1: the only size a 1-GPU box allows).
+    Gradients must equal the un-wrapped model's bit for bit, buckets must tile the flat buffer, and the
+    compute stream must be ordered after the collectives."""
+    import os
+    import torch.distributed as dist
+    from video_tokenizer_amd.parallel import DataParallelTokenizer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        cfg = O.make_cfg("tiny")
+        model, _ = build(cfg)
+        x = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 31)).cuda()
+        w = torch.from_numpy(gen.normal(tuple(x.shape), 32)).cuda()
+
+        def run(net):
+            for p in model.parameters():
+                p.grad = None
+            out = net(x)
+            ((out["pred_frames"] * w).sum() + 0.7 * out["loss_q"]).backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+        plain = run(model)
+        dp = DataParallelTokenizer(model, bucket_bytes=8 << 20)
+        red = model._engine.reducer
+        wrapped = run(dp)
+        assert red.launched and red.launched[0][0] == 0 and red.launched[-1][1] == model._engine.flat_grad.numel()
+        assert all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:])) and len(red.launched) >= 3
+        for n in plain:
+            assert torch.equal(plain[n], wrapped[n]), n
+        model._engine.reducer = None
+    finally:
+        if created:
+            dist.destroy_process_group()

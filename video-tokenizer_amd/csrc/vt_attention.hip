@@ -31,7 +31,8 @@ constexpr int TILE = 64 * 128;  // bytes per [64][64] bf16 tile
 
 __device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-__device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, char* lds, int tid, int wave) {
+// LDS-DMA through inline asm (see glds16_asm): callers drain with dma_drain() before the publishing barrier
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, unsigned lds, int tid, int wave) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int slot = i * 256 + tid;
@@ -39,7 +40,7 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t 
         const int lc = (slot & 7) ^ fsw(row);
         int gr = row0 + row;
         gr = gr < L ? gr : L - 1;
-        glds16(src + (int64_t)gr * rs + lc * 8, lds + (i * 256 + wave * 64) * 16);
+        glds16_asm(src + (int64_t)gr * rs + lc * 8, lds + (i * 256 + wave * 64) * 16);
     }
 }
 
@@ -174,8 +175,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
 
     const int nt = (L + 63) / 64;
     // LDS: [buffer 0: K | V][buffer 1: K | V]
-    stage64(kb, rs, 0, L, smem, tid, wave);
-    stage64(vb, rs, 0, L, smem + TILE, tid, wave);
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    stage64(kb, rs, 0, L, sbase, tid, wave);
+    stage64(vb, rs, 0, L, sbase + TILE, tid, wave);
+    dma_drain();
     __syncthreads();
 
     // hot loop: full 64-key tiles only; a ragged last tile (L % 64 != 0) runs once, after the loop, so its masking
@@ -184,11 +187,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restri
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            stage64(kb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE, tid, wave);
-            stage64(vb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+            stage64(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
+            stage64(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
         const char* kl = smem + cur * 2 * TILE;
         fwd_tile<false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
+        dma_drain();
         __syncthreads();
     }
     if (nfull < nt) {
@@ -283,19 +287,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
 
     const int nt = (L + 63) / 64;
     // LDS: [buffer 0: K | V][buffer 1: K | V]
-    stage64(kb, rs, 0, L, smem, tid, wave);
-    stage64(vb, rs, 0, L, smem + TILE, tid, wave);
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    stage64(kb, rs, 0, L, sbase, tid, wave);
+    stage64(vb, rs, 0, L, sbase + TILE, tid, wave);
+    dma_drain();
     __syncthreads();
 
     const int nfull = (L & 63) ? nt - 1 : nt;
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            stage64(kb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE, tid, wave);
-            stage64(vb, rs, (t + 1) * 64, L, smem + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+            stage64(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
+            stage64(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
         const char* kl = smem + cur * 2 * TILE;
         dq_tile<false>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, t * 64, L, scale_log2e, lane, half);
+        dma_drain();
         __syncthreads();
     }
     if (nfull < nt) {
@@ -381,17 +388,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     // LDS: per buffer  Q tile | dO tile | lse2[64] | delta[64]
     constexpr int BUF = 2 * TILE + 512;
     const int nt = (L + 63) / 64;
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     auto stage = [&](int t, int buf) {
-        char* base = smem + buf * BUF;
+        const unsigned base = sbase + buf * BUF;
         stage64(qb, rs, t * 64, L, base, tid, wave);
         stage64(dob, ors, t * 64, L, base + TILE, tid, wave);
         if (wave < 2) {  // wave 0: lse2[64], wave 1: delta[64] by 4-byte LDS-DMA (rows past L clamped; masked at use)
             int qq = t * 64 + lane;
             qq = qq < L ? qq : L - 1;
-            glds4((wave == 0 ? lse_b : del_b) + qq, base + 2 * TILE + wave * 256);
+            glds4_asm((wave == 0 ? lse_b : del_b) + qq, base + 2 * TILE + wave * 256);
         }
     };
     stage(0, 0);
+    dma_drain();
     __syncthreads();
 
     const int nfull = (L & 63) ? nt - 1 : nt;
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const int cur = t & 1;
         if (t + 1 < nt) stage(t + 1, cur ^ 1);
         dkv_tile<false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
+        dma_drain();
         __syncthreads();
     }
     if (nfull < nt) dkv_tile<true>(smem + (nfull & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);

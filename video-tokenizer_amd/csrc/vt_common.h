@@ -65,6 +65,20 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_byte_a
         : "v"(gsrc), "s"(lds_byte_addr)
         : "memory");
 }
+__device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+// drain this wave's LDS-DMA before a barrier that publishes the staged tile (the compiler does not see asm DMAs)
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(VT_LDS const char*)p; }
 
 // transposed LDS read: per 16-lane group a 4-row x 16-col block of 16-bit elements; lane i of the

@@ -83,7 +83,19 @@ struct vtTokenizer {
     size_t patches, zb, zproj, vq_E, vq_wnorm, vq_zn, vq_znorm, vq_idx, vq_rz, vq_rzpad, vq_losses, vq_ws, encoded_int;
     size_t hN, meanH, rstdH, yrows;
     // backward scratch
-    size_t dX, dXb_a, dXb_b, du, dh, dob, dqkv, delta, ln_ws, cs_ws, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec;
+    size_t dX, dh, dob, delta, ln_ws, cs_ws, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec;
+    // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
+    // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
+    // is the next block's dx_out set).
+    struct GradSet { size_t dx_out, dx_mid, du, dqkv; };
+    static constexpr int WG_BATCH = 4;
+    GradSet gs[WG_BATCH + 1];
+    // host-side state of an in-flight backward
+    std::vector<vtGemmTN> pending;
+    int pending_blocks = 0;   // blocks whose wgrads sit in `pending`
+    int set_idx = 0;          // gradient set of the block processed next
+    int final_through = 0;    // stages [0, final_through) have complete gradients
+    int pending_first_stage = 0;
 };
 
 #define WS(T, off) ((T*)((char*)ws + (off)))
@@ -157,9 +169,13 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
     t->encoded_int = a.take(Mqp * D * 4);
     t->hN = a.take(Mvp * D * 2); t->meanH = a.take(Mvp * 4); t->rstdH = a.take(Mvp * 4);
     t->yrows = a.take(Mvp * Kp * 4);
-    t->dX = a.take(Mp * D * 4); t->dXb_a = a.take(Mp * D * 2); t->dXb_b = a.take(Mp * D * 2);
-    t->du = a.take(Mp * t->D4 * 2); t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
-    t->dqkv = a.take(Mp * t->D3 * 2); t->delta = a.take((size_t)c.B * c.H * t->L * 4);
+    t->dX = a.take(Mp * D * 4);
+    for (auto& g : t->gs) {
+        g.dx_out = a.take(Mp * D * 2); g.dx_mid = a.take(Mp * D * 2);
+        g.du = a.take(Mp * t->D4 * 2); g.dqkv = a.take(Mp * t->D3 * 2);
+    }
+    t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
+    t->delta = a.take((size_t)c.B * c.H * t->L * 4);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
     t->dY = a.take(Mvp * Kp * 2); t->dhN = a.take(Mvp * D * 2);
@@ -334,24 +350,39 @@ static vtGemmTN tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M
     return p;
 }
 
-// Backward of one block.  In: dX (fp32) and dXb_a (bf16) hold dL/dx_out.  Out: the same two buffers hold dL/dx_in.
+static int flush_wgrads(vtTokenizer* t, int stage_done, vtStream s) {
+    for (size_t i = 0; i < t->pending.size(); i += VT_TN_MAX_GROUP) {
+        const int n = (int)((t->pending.size() - i) < VT_TN_MAX_GROUP ? (t->pending.size() - i) : VT_TN_MAX_GROUP);
+        TRY(vt_gemm_tn_grouped(t->pending.data() + i, n, s));
+    }
+    t->pending.clear();
+    t->pending_blocks = 0;
+    t->final_through = stage_done;
+    return VT_OK;
+}
+
+// Backward of one block.  In: dX (fp32) and gs[set].dx_out (bf16) hold dL/dx_out.  Out: dX holds dL/dx_in and its bf16
+// copy goes to gs[next set].dx_out.  The four weight-gradient GEMMs are queued (t->pending), not launched.
 // prev_bias_grad: where sum_rows(dL/dx_in) goes (= bias gradient of whatever produced x_in), may be NULL.
 static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTensors& w, const vtBlockTensors& gr, const float* x_in,
-                          float* fc2_b_grad_done_marker, float* prev_bias_grad, void* ws, vtStream s) {
-    (void)fc2_b_grad_done_marker;
+                          float* prev_bias_grad, void* ws, vtStream s) {
     const vtTokenizerConfig& c = t->c;
     const int M = t->M, Mp = t->Mp, D = c.D, D3 = t->D3, D4 = t->D4;
     const vtRowMap id = {0, 0, 0};
+    const vtTokenizer::GradSet& g0 = t->gs[t->set_idx];
+    const vtTokenizer::GradSet& g1 = t->gs[(t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1)];
     float* dX = WS(float, t->dX);
-    void* dXa = WS(void, t->dXb_a);
-    void* dXm = WS(void, t->dXb_b);
+    void* dXa = WS(void, g0.dx_out);
+    void* dXm = WS(void, g0.dx_mid);
+    void* du = WS(void, g0.du);
+    void* dqkv = WS(void, g0.dqkv);
     // fc2 dgrad fused with GELU': du = (dx_out . W2) * gelu'(u)
-    vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, WS(void, t->du), D4);
+    vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, du, D4);
     g.aux = WS(void, b.u); g.ldaux = D4;
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_colsum(WS(void, t->du), 1, D4, id, M, D4, gr.fc1_b, WS(void, t->cs_ws), s));
+    TRY(vt_colsum(du, 1, D4, id, M, D4, gr.fc1_b, WS(void, t->cs_ws), s));
     // fc1 dgrad
-    g = nt(WS(void, t->du), D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
+    g = nt(du, D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     // LayerNorm2 backward + residual: dx_mid = dx_out + ln_bwd(dh2) (in place in dX; bf16 copy -> dXm); column sum = proj bias grad
     TRY(vt_layernorm_bwd(WS(void, t->dh), WS(float, b.x_mid), id, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, M, D, dX, dXm,
@@ -360,26 +391,26 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     g = nt(dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
     // attention backward
-    TRY(vt_attention_bwd(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, 64, WS(void, t->dqkv), WS(float, t->delta), s));
+    TRY(vt_attention_bwd(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, 64, dqkv, WS(float, t->delta), s));
     // qkv dgrad
-    g = nt(WS(void, t->dqkv), D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
+    g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
-    // the block's four weight gradients in one grouped launch (432 tiles at D=768: fills the chip, no split-K)
-    vtGemmTN grp[4] = {
-        tn(dXa, D, WS(void, b.g), D4, Mp, D, D4, gr.fc2_w, D4),
-        tn(WS(void, t->du), D4, WS(void, b.h2), D, Mp, D4, D, gr.fc1_w, D),
-        tn(dXm, D, WS(void, b.o), D, Mp, D, D, gr.proj_w, D),
-        tn(WS(void, t->dqkv), D3, WS(void, b.h1), D, Mp, D3, D, gr.qkv_w, D),
-    };
-    TRY(vt_gemm_tn_grouped(grp, 4, s));
-    // LayerNorm1 backward + residual: dx_in = dx_mid + ln_bwd(dh) (in place; bf16 copy -> dXa)
-    TRY(vt_layernorm_bwd(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, dXa, gr.norm1_w,
-                         gr.norm1_b, prev_bias_grad, WS(void, t->ln_ws), s));
+    // the block's four weight gradients: queued for the grouped launch
+    t->pending.push_back(tn(dXa, D, WS(void, b.g), D4, Mp, D, D4, gr.fc2_w, D4));
+    t->pending.push_back(tn(du, D4, WS(void, b.h2), D, Mp, D4, D, gr.fc1_w, D));
+    t->pending.push_back(tn(dXm, D, WS(void, b.o), D, Mp, D, D, gr.proj_w, D));
+    t->pending.push_back(tn(dqkv, D3, WS(void, b.h1), D, Mp, D3, D, gr.qkv_w, D));
+    t->pending_blocks++;
+    // LayerNorm1 backward + residual: dx_in = dx_mid + ln_bwd(dh) (in place; bf16 copy -> next set's dx_out)
+    TRY(vt_layernorm_bwd(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
+                         gr.norm1_w, gr.norm1_b, prev_bias_grad, WS(void, t->ln_ws), s));
+    t->set_idx = (t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1);
     return VT_OK;
 }
 
 extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P, const float* d_pred, const float* gscal, void* ws,
-                                     const vtTokenizerTensors* G, int32_t stage_begin, int32_t stage_end, vtStream s) {
+                                     const vtTokenizerTensors* G, int32_t stage_begin, int32_t stage_end, int32_t* final_through,
+                                     vtStream s) {
     VT_CHECK_ARG(t && P && ws && G && G->enc_blocks && G->dec_blocks, "vt_tokenizer_backward: null pointer");
     const vtTokenizerConfig& c = t->c;
     const int nstage = vt_tokenizer_num_backward_stages(t);
@@ -394,6 +425,8 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
     float* dX = WS(float, t->dX);
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
+            t->pending.clear();
+            t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
             // ---- head: d_pred -> patch rows (c,dt,dy,dx) -> dgrad / wgrad -> LayerNorm backward into the last Nv rows
             VT_CHECK_ARG(d_pred, "vt_tokenizer_backward: stage 0 needs d_pred");
             TRY(vt_patchify(d_pred, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->dY), s));
@@ -405,17 +438,19 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(vt_colsum(WS(void, t->dY), 1, Kp, id, t->Mv, Kp, WS(float, t->tmp_vec), WS(void, t->cs_ws), s));
             hipLaunchKernelGGL(scatter_f32_kernel, dim3((Kp + 255) / 256), dim3(256), 0, hs, WS(float, t->tmp_vec), WS(int32_t, t->perm), Kp, G->head_b);
             (void)hipMemsetAsync(dX, 0, (size_t)t->Mp * D * 4, hs);
-            (void)hipMemsetAsync(WS(void, t->dXb_a), 0, (size_t)t->Mp * D * 2, hs);
+            (void)hipMemsetAsync(WS(void, t->gs[0].dx_out), 0, (size_t)t->Mp * D * 2, hs);
             // rows < Nq of the last decoder block's output are dropped by the slice => zero gradient
             TRY(vt_layernorm_bwd(WS(void, t->dhN), WS(float, t->x_dec[c.depth_dec]), vmap, P->head_norm_w, WS(float, t->meanH), WS(float, t->rstdH),
-                                 nullptr, t->Mv, D, dX, WS(void, t->dXb_a), G->head_norm_w, G->head_norm_b,
+                                 nullptr, t->Mv, D, dX, WS(void, t->gs[0].dx_out), G->head_norm_w, G->head_norm_b,
                                  nullptr, WS(void, t->ln_ws), s));
             // fc2 bias grad of the last decoder block = column sum of dL/dx_out (all rows; zero rows add nothing)
             TRY(vt_colsum(dX, 0, D, id, t->M, D, G->dec_blocks[c.depth_dec - 1].fc2_b, WS(void, t->cs_ws), s));
+            t->final_through = 1;
         } else if (st <= c.depth_dec) {
             const int i = c.depth_dec - st;  // decoder blocks, last first
             float* prev = i > 0 ? G->dec_blocks[i - 1].fc2_b : nullptr;
-            TRY(block_backward(t, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), nullptr, prev, ws, s));
+            TRY(block_backward(t, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), prev, ws, s));
+            if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) TRY(flush_wgrads(t, st + 1, s));
         } else if (st == c.depth_dec + 1) {
             // ---- bottleneck.  dX holds dL/d(decoder input sequence)
             if (G->dec_token_type) TRY(vt_colsum(dX, 0, D, vmap, t->Mv, D, G->dec_token_type, WS(void, t->cs_ws), s));
@@ -438,15 +473,18 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             w.p_lim = c.d;
             TRY(vt_gemm_tn_grouped(&w, 1, s));
             (void)hipMemsetAsync(dX, 0, (size_t)t->Mp * D * 4, hs);
-            (void)hipMemsetAsync(WS(void, t->dXb_a), 0, (size_t)t->Mp * D * 2, hs);
+            t->set_idx = 0;
+            (void)hipMemsetAsync(WS(void, t->gs[0].dx_out), 0, (size_t)t->Mp * D * 2, hs);
             g = nt(WS(void, t->dz_pad), 64, WS(void, t->in_wt), 64, t->Mq, D, 64, VT_EPI_F32, dX, D);
-            g.out2 = WS(void, t->dXb_a); g.ldo2 = D; g.omap = qmap;
+            g.out2 = WS(void, t->gs[0].dx_out); g.ldo2 = D; g.omap = qmap;
             TRY(vt_gemm_nt(&g, s));
             TRY(vt_colsum(dX, 0, D, id, t->M, D, G->enc_blocks[c.depth_enc - 1].fc2_b, WS(void, t->cs_ws), s));
+            t->final_through = st + 1;
         } else if (st <= c.depth_dec + 1 + c.depth_enc) {
             const int i = c.depth_enc - (st - c.depth_dec - 1);
             float* prev = i > 0 ? G->enc_blocks[i - 1].fc2_b : nullptr;
-            TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), nullptr, prev, ws, s));
+            TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
+            if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) TRY(flush_wgrads(t, st + 1, s));
         } else {
             // ---- patch embed + learned queries.  dX holds dL/d(encoder input sequence)
             TRY(vt_batch_sum(dX, qmap, c.B, Nq, D, G->enc_query, s));
@@ -454,8 +492,10 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(vt_colsum(WS(void, t->dTok), 1, D, id, t->Mv, D, G->pe_b, WS(void, t->cs_ws), s));
             vtGemmTN w = tn(WS(void, t->dTok), D, WS(void, t->patches), Kp, t->Mvp, D, Kp, G->pe_w, Kp);
             TRY(vt_gemm_tn_grouped(&w, 1, s));
+            t->final_through = st + 1;
         }
     }
+    if (final_through) *final_through = t->final_through;
     VT_CHECK_LAUNCH("vt_tokenizer_backward");
     return VT_OK;
 }

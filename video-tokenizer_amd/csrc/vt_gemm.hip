@@ -274,13 +274,10 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     } else {
         VT_CHECK_ARG(p.omap.grp == 0, "vt_gemm_nt: output row map only with VT_EPI_F32");
     }
-    // auto dispatch (measured on MI355X, tools/gemm_bench.py): the 192x192 3-stage kernel wins when its tiles fit
-    // the 256 CUs in one wave (N = 768 at M = 12288) or when K is long enough to amortise its un-overlapped
-    // epilogue (1 workgroup/CU); short-K / wide-N shapes with heavy epilogues (fc1+GELU) stay on 128x128 tiles
-    // whose 2 workgroups per CU overlap one's epilogue with the other's main loop.
-    const int64_t tiles192 = (int64_t)((p.M + 191) / 192) * ((p.N + 191) / 192);
-    const bool big = g_gemm_variant == 2 ||
-                     (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192 && (tiles192 <= 256 || p.K >= 1536));
+    // auto dispatch (measured on MI355X, tools/gemm_bench.py, profiles/r01_*_gemm_variants_microbench.log): the
+    // 192x192 3-stage kernel is ahead on every training-step shape (N = 768: one tile per CU, no tail wave);
+    // problems smaller than one tile (bottleneck in_linear N = 24, out_linear K-padded) stay on 128x128 tiles.
+    const bool big = g_gemm_variant == 2 || (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192);
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
@@ -311,7 +308,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     TNArgs a;
     a.n = n;
     a.tile_start[0] = 0;
-    bool big = g_gemm_variant == 2;  // auto: 128x128 tiles (432 tiles per transformer block fill the chip; 192 tiles of 192x192 would not)
+    bool big = g_gemm_variant != 1;  // auto: 192x192 tiles when every problem of the group is at least one tile
     for (int g = 0; g < n; ++g) {
         const vtGemmTN& p = ph[g];
         VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_tn_grouped[%d]: null operand", g);
@@ -323,6 +320,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
         a.p[g] = p;
         const int tp = (p.p_lim + BM - 1) / BM, tq = (p.q_lim + BN - 1) / BN;
         a.tile_start[g + 1] = a.tile_start[g] + tp * tq;
+        if (g_gemm_variant == 0 && (p.p_lim < 192 || p.q_lim < 192)) big = false;
     }
     if (big) {
         int rc = vt_gemm192_init();

@@ -82,6 +82,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
         stage_nt192(B, p.ldb, n0, p.N, TK, sbase + STAGE_BYTES + OP_BYTES, tid, wave);
     }
     const int fr = lane & 15, fq = lane >> 4;
+    // byte offset of this lane's first A / B fragment inside an operand tile, for k-step 0 and 1.  The swizzle term
+    // ((row>>1)&7) does not depend on the 16-row fragment index (16 rows = 8 swizzle periods), so fragment i sits at
+    // +i*2048 bytes: an instruction immediate.
+    const int arow = wm * 96 + fr, brow = wn * 48 + fr;
+    const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4), a_off1 = arow * 128 + (((4 + fq) ^ ((arow >> 1) & 7)) << 4);
+    const unsigned b_off0 = brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4), b_off1 = brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4);
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
         if (t + 1 < nt) wait_vmcnt6(); else wait_vmcnt0();  // this thread's pieces of tile t have landed
@@ -91,36 +97,47 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
             stage_nt192(A, p.lda, m0, p.M, (t + 2) * TK, sbase + nx * STAGE_BYTES, tid, wave);
             stage_nt192(B, p.ldb, n0, p.N, (t + 2) * TK, sbase + nx * STAGE_BYTES + OP_BYTES, tid, wave);
         }
-        const char* la = smem + cur * STAGE_BYTES;
-        const char* lb = la + OP_BYTES;
-        // all 18 fragment reads of the K-tile are issued first (two register sets), in the order the MFMAs consume
-        // them; the MFMAs then start behind counted lgkmcnt waits while later reads are still in flight
-        // (the LGKM counter is 4 bits: keep <= 14 reads in flight so hipcc can emit counted waits)
-        bf16x8 af[2][6], bfv[2][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) bfv[0][j] = frag_nt192(lb, wn * 48 + j * 16 + fr, fq);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) af[0][i] = frag_nt192(la, wm * 96 + i * 16 + fr, fq);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) bfv[1][j] = frag_nt192(lb, wn * 48 + j * 16 + fr, 4 + fq);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[1][i] = frag_nt192(la, wm * 96 + i * 16 + fr, 4 + fq);
+        // Fragment reads are hand-issued (inline asm) so that the LDS waits can be COUNTED: hipcc emits lgkmcnt(0)
+        // for ds_read_b128 fragments in this loop.  LDS returns in order, so after issuing reads r0..r13 a
+        // wait lgkmcnt(13 - k) means r0..rk have landed.  Each wait is followed by sched_barrier(0) so no MFMA is
+        // hoisted above it.  Order: b0[0..2] a0[0..5] | b1[0..2] a1[0..1]   (14 in flight: 4-bit counter)
+        const unsigned ta = sbase + cur * STAGE_BYTES;
+        const unsigned a_k0 = ta + a_off0, a_k1 = ta + a_off1, b_k0 = ta + OP_BYTES + b_off0, b_k1 = ta + OP_BYTES + b_off1;
+        bf16x8 a0[6], b0[3], a1[6], b1[3];
+#define VT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define VT_LGKM(n)                                            \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0)
+#define VT_ROW(accrow, bb, aa)                                                                   \
+    accrow[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[0], aa, accrow[0], 0, 0, 0);          \
+    accrow[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[1], aa, accrow[1], 0, 0, 0);          \
+    accrow[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[2], aa, accrow[2], 0, 0, 0)
+        VT_DSR(b0[0], b_k0, 0); VT_DSR(b0[1], b_k0, 2048); VT_DSR(b0[2], b_k0, 4096);
+        VT_DSR(a0[0], a_k0, 0); VT_DSR(a0[1], a_k0, 2048); VT_DSR(a0[2], a_k0, 4096);
+        VT_DSR(a0[3], a_k0, 6144); VT_DSR(a0[4], a_k0, 8192); VT_DSR(a0[5], a_k0, 10240);
+        VT_DSR(b1[0], b_k1, 0); VT_DSR(b1[1], b_k1, 2048); VT_DSR(b1[2], b_k1, 4096);
+        VT_DSR(a1[0], a_k1, 0); VT_DSR(a1[1], a_k1, 2048);
+        VT_LGKM(10); VT_ROW(acc[0], b0, a0[0]);
+        VT_LGKM(9);  VT_ROW(acc[1], b0, a0[1]);
+        VT_LGKM(8);  VT_ROW(acc[2], b0, a0[2]);
+        VT_LGKM(7);  VT_ROW(acc[3], b0, a0[3]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[0][j], af[0][i], acc[i][j], 0, 0, 0);
+        VT_DSR(a1[2], a_k1, 4096); VT_DSR(a1[3], a_k1, 6144);           // 6 + 2 in flight
+        VT_LGKM(7);  VT_ROW(acc[4], b0, a0[4]);
+        VT_LGKM(6);  VT_ROW(acc[5], b0, a0[5]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 2; i < 6; ++i) af[1][i] = frag_nt192(la, wm * 96 + i * 16 + fr, 4 + fq);
+        VT_DSR(a1[4], a_k1, 8192); VT_DSR(a1[5], a_k1, 10240);          // b1 x3, a1[0..3], + 2 = 9 in flight
+        VT_LGKM(5);  VT_ROW(acc[0], b1, a1[0]);
+        VT_LGKM(4);  VT_ROW(acc[1], b1, a1[1]);
+        VT_LGKM(3);  VT_ROW(acc[2], b1, a1[2]);
+        VT_LGKM(2);  VT_ROW(acc[3], b1, a1[3]);
+        VT_LGKM(1);  VT_ROW(acc[4], b1, a1[4]);
+        VT_LGKM(0);  VT_ROW(acc[5], b1, a1[5]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[1][j], af[1][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+#undef VT_DSR
+#undef VT_LGKM
+#undef VT_ROW
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 

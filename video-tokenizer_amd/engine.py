@@ -290,11 +290,17 @@ class TokenizerFunction(torch.autograd.Function):
         lo_ptr, hi_ptr = engine.flat_grad.data_ptr(), engine.flat_grad.data_ptr() + engine.flat_grad.numel() * 4
         aliased = {n for n in engine.apply_names if named[n].grad is not None and lo_ptr <= named[n].grad.data_ptr() < hi_ptr}
         saved = engine.flat_grad.clone() if aliased else None
-        for stage in range(st.nstages):
+        final = ctypes.c_int32(0)
+        done = 0
+        # without a reducer the whole backward is one enqueue; with one, stage by stage so finished slices can be reduced
+        chunks = [(s_, s_ + 1) for s_ in range(st.nstages)] if red is not None else [(0, st.nstages)]
+        for lo_s, hi_s in chunks:
             hip.check(lib.vt_tokenizer_backward(st.handle, ctypes.byref(ps.struct), hip.ptr(d_pred), hip.ptr(gscal), hip.ptr(st.ws),
-                                                ctypes.byref(engine.grad_struct.struct), stage, stage + 1, hip.stream()), "vt_tokenizer_backward")
-            if red is not None:
-                red.segment_ready(engine.flat_grad, *engine.segments[stage])
+                                                ctypes.byref(engine.grad_struct.struct), lo_s, hi_s, ctypes.byref(final), hip.stream()),
+                      "vt_tokenizer_backward")
+            while red is not None and done < final.value:  # stages whose gradients are final (deferred wgrads flushed)
+                red.segment_ready(engine.flat_grad, *engine.segments[done])
+                done += 1
         if red is not None:
             red.finish()
         if saved is not None:

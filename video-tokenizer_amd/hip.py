@@ -13,7 +13,7 @@ _lib = None
 c_i32, c_i64, c_f32, c_u64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t
 
 EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_BF16_DGELU = 0, 1, 2, 3
-TN_MAX_GROUP = 8
+TN_MAX_GROUP = 16
 
 
 class RowMap(ctypes.Structure):
@@ -103,7 +103,7 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_decode": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_codes_to_encoded": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_num_backward_stages": (c_i32, [c_vp]),
-    "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, c_vp]),
+    "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, ctypes.POINTER(c_i32), c_vp]),
 }
 
 
