@@ -81,6 +81,16 @@ def time_dominant_kernel(B, c, reps=20):
     return tot_f / tot_t / 1e12, per, tot_t
 
 
+def measured_traffic():
+    """HBM-side bytes per launch of the dominant kernel from PMC counters (cannot be collected inside this process):
+    the rocprofv3 passes of tools/pmc_traffic.sh, committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemm_nt192.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return int(json.load(f)["traffic_bytes_per_launch_mean"])
+
+
 def cpu_baseline(c, sd_seed=7):
     """The oracle (CPU restatement, fp32, reference semantics) timed on this host's cores: ONE clip of the
     same workload, forward + backward, stochastic=False index path (multinomial is not the cost)."""
@@ -191,8 +201,8 @@ def main():
         }
         if not a.no_roofline:
             ach, per, _ = time_dominant_kernel(B, c)
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<VT_EPI_BF16> (qkv fwd + fc1/proj/qkv dgrad)", "achieved": round(ach, 1),
-                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt192_kernel<VT_EPI_BF16> (qkv fwd + fc1/proj/qkv dgrad)", "achieved": round(ach, 1),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
                                "per_shape": per, "whole_step_frac": round(clips_s / world * f_clip / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(c)

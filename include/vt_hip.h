@@ -126,6 +126,10 @@ int vt_colsum(const void* src, int32_t src_is_bf16, int64_t ld, vtRowMap map, in
 /* out[j,:] = sum_b src[map(b*n + j), :]  -- gradient of encoder_latent_query_embed, which
  * larp_tokenizer.py:410 broadcasts over the batch with .repeat(b,1,1) */
 int vt_batch_sum(const float* src, vtRowMap map, int32_t batch, int32_t n, int32_t dim, float* out, vtStream stream);
+/* zero rows map(r), r < rows, of an fp32 matrix and/or its bf16 twin (rows a sliced backward does not write) */
+int vt_zero_rows(float* a, void* b_bf16, vtRowMap map, int64_t rows, int32_t dim, vtStream stream);
+/* out[c] = sum_s slabs[s*slab_stride + c], fixed order (combine split-M partial weight gradients) */
+int vt_sum_slabs(const float* slabs, int32_t nslab, int64_t slab_stride, int32_t width, float* out, vtStream stream);
 /* dst[r,:] = bf16(src[map(r),:]) */
 int vt_cast_rows(const float* src, vtRowMap map, int64_t rows, int32_t dim, void* dst_bf16, int64_t ldd, vtStream stream);
 /* dst[b*seq + off + j, :] = src[b*n + j, :] + table[j, :] + vec[:]   (each term optional)

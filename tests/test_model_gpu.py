@@ -162,3 +162,68 @@ def test_data_parallel_wrapper_single_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_config_A_full_depth_matches_oracle():
+    """BASELINE configs[0]: cfgs/larp_tokenizer.yaml geometry on 2x64x64 clips, bs=1, full 12+12 depth (L = 16 + 1024 =
+    1040: not a multiple of any tile).  Forward + a few gradients against the CPU oracle (fp32 reference semantics AND
+    the bf16-emulating variant)."""
+    cfg = O.make_cfg("A")
+    model, sd = build(cfg, seed=3)
+    x = torch.from_numpy(gen.video_clips(1, cfg["frame_num"], cfg["input_size"], 41))
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 42))
+    model.train()
+    out = model(x.cuda())
+    ((out["pred_frames"] * w.cuda()).sum() + 0.7 * out["loss_q"]).backward()
+    torch.cuda.synchronize()
+    idx = out["bottleneck_rep"].cpu()
+    names = ["final_layer.linear.weight", "decoder.blocks.11.mlp.fc2.weight", "decoder.blocks.0.attn.qkv.weight", "bottleneck.out_linear.weight",
+             "bottleneck.regularizer.embedding.weight", "bottleneck.in_linear.weight", "encoder.blocks.11.mlp.fc1.weight",
+             "encoder.blocks.0.norm1.weight", "encoder_latent_query_embed", "x_embedder.proj.weight"]
+    p = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_idx=idx)
+    ((ref["pred_frames"] * w).sum() + 0.7 * ref["loss_q"]).backward()
+    assert rel(out["pred_frames"].cpu(), ref["pred_frames"].detach()) < 3e-2
+    assert rel(out["encoded"].cpu(), ref["encoded"].detach()) < 3e-2
+    with torch.no_grad():
+        ref32 = O.tokenizer_forward(sd, cfg, x, "L", emu=False)
+    assert rel(out["pred_frames"].cpu(), ref32["pred_frames"]) < 8e-2          # fp32 CPU reference semantics, stated tolerance
+    assert (ref32["bottleneck_rep"] == idx).float().mean().item() >= 0.95      # 24 bf16 blocks deep: only near-ties differ
+    named = dict(model.named_parameters())
+    bad = [(n, rel(named[n].grad.cpu(), p[n].grad)) for n in names]
+    assert all(e < 8e-2 for _, e in bad), bad
+
+
+@pytest.mark.parametrize("name", ["C", "D"])
+def test_f256_geometries_size_independent_properties(name):
+    """BASELINE configs[2], [3] (pt4 p8, 6+6 blocks, d=16, 512 / 1024 latent tokens) at full 16x128x128 size, where the
+    CPU oracle is too slow: properties that hold at any size."""
+    cfg = O.make_cfg(name)
+    model, sd = build(cfg, seed=5, stochastic=True)
+    x = torch.from_numpy(gen.video_clips(2, 16, 128, 51)).cuda()
+    model.eval()
+    model.set_vq_eval_deterministic(True)
+    with torch.no_grad():
+        a = model(x)
+        b = model(x)
+        v = model.decode_from_bottleneck(a["bottleneck_rep"])
+        single = model(x[1:2])
+    torch.cuda.synchronize()
+    assert a["bottleneck_rep"].shape == (2, cfg["bottleneck_token_num"]) and a["pred_frames"].shape == x.shape
+    assert torch.equal(a["bottleneck_rep"], b["bottleneck_rep"]) and torch.equal(a["pred_frames"], b["pred_frames"])  # deterministic
+    assert torch.equal(a["pred_frames"], v)                      # indices -> codebook -> decode reproduces the reconstruction
+    assert int(a["bottleneck_rep"].min()) >= 0 and int(a["bottleneck_rep"].max()) < cfg["codebook_size"]
+    # clips are independent: batch of 2 == each clip alone (same kernels, same reduction order per clip)
+    assert torch.equal(a["bottleneck_rep"][1:2], single["bottleneck_rep"])
+    assert rel(a["pred_frames"][1:2], single["pred_frames"]) < 1e-6
+    # codebook rows are unit vectors; quantised latents are codebook rows; commit loss == mean squared distance
+    emb, rz, uz = a["emb"], a["regularized_z"], a["unregularized_z"]
+    assert torch.allclose(emb.norm(dim=-1), torch.ones_like(emb[:, 0]), atol=1e-5)
+    q = emb[a["bottleneck_rep"].reshape(-1)]
+    assert torch.equal(rz.reshape(-1, emb.shape[1]), uz.reshape(-1, emb.shape[1]) + (q - uz.reshape(-1, emb.shape[1])))
+    mse = ((q - uz.reshape(-1, emb.shape[1])) ** 2).mean()
+    assert abs(a["loss_commit"].item() - mse.item()) < 1e-6 * max(1.0, mse.item()) and abs(a["loss_q"].item() - 1.25 * mse.item()) < 1e-5
+    # argmax really is the best code: no other code has a larger cosine (checked densely for 64 tokens)
+    cos = uz.reshape(-1, emb.shape[1])[:64] @ emb.t()
+    assert torch.equal(cos.argmax(dim=-1), a["bottleneck_rep"].reshape(-1)[:64])

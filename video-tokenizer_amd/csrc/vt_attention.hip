@@ -134,10 +134,10 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
             ps += p;
         }
     lsum = lsum * alpha + ps;
-    if (!__all(alpha == 1.0f)) {  // the running max moved for some query of this wave: rescale O
+    // unconditional: 16 packed multiplies; a "skip when alpha == 1" branch costs more (the compiler then copies the
+    // 32 accumulator registers around the branch every tile)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-    }
+    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -152,7 +152,7 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
                                                            int L, int H, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;

@@ -83,7 +83,7 @@ struct vtTokenizer {
     size_t patches, zb, zproj, vq_E, vq_wnorm, vq_zn, vq_znorm, vq_idx, vq_rz, vq_rzpad, vq_losses, vq_ws, encoded_int;
     size_t hN, meanH, rstdH, yrows;
     // backward scratch
-    size_t dX, dh, dob, delta, ln_ws, cs_ws, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec;
+    size_t dX, dh, dob, delta, ln_ws, cs_ws, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
     // is the next block's dx_out set).
@@ -182,6 +182,7 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
     t->dEncb = a.take(Mqp * D * 2); t->d_rz = a.take(Mqp * 64 * 4); t->dz_pad = a.take(Mqp * 64 * 2);
     t->dTok = a.take(Mvp * D * 2);
     t->tmp_vec = a.take((Kp > (size_t)t->D4 ? Kp : t->D4) * 4);
+    t->wg_slabs = a.take((size_t)16 * D * 64 * 4);  // split-M partials of the two skinny (d-wide) weight gradients
     t->ws_bytes = a.off;
     *out = t;
     return VT_OK;
@@ -350,6 +351,31 @@ static vtGemmTN tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M
     return p;
 }
 
+// A weight gradient whose output is only a few tiles (bottleneck in/out_linear: D x d) would occupy a handful of the
+// 256 CUs for the whole token dimension.  Split the tokens into up to 16 slabs, run them as one grouped launch into
+// partial outputs, and add the slabs in a fixed order.
+static int skinny_wgrad(vtTokenizer* t, vtGemmTN w, void* ws, vtStream s) {
+    int ns = 16;
+    while (ns > 1 && (w.M % (64 * ns)) != 0) ns >>= 1;
+    if (ns == 1) return vt_gemm_tn_grouped(&w, 1, s);
+    const int rows = w.M / ns;
+    const size_t slab = (size_t)w.p_lim * w.q_lim;
+    vtGemmTN pr[16];
+    float* part = WS(float, t->wg_slabs);
+    for (int i = 0; i < ns; ++i) {
+        pr[i] = w;
+        pr[i].A = (const char*)w.A + (size_t)i * rows * w.lda * 2;
+        pr[i].B = (const char*)w.B + (size_t)i * rows * w.ldb * 2;
+        pr[i].M = rows;
+        pr[i].out = part + i * slab;
+        pr[i].ldo = w.q_lim;
+    }
+    TRY(vt_gemm_tn_grouped(pr, ns, s));
+    if (w.ldo == w.q_lim) return vt_sum_slabs(part, ns, (int64_t)slab, (int)slab, w.out, s);
+    vt_set_error("skinny_wgrad: output must be dense");
+    return VT_ERR_INVALID;
+}
+
 static int flush_wgrads(vtTokenizer* t, int stage_done, vtStream s) {
     for (size_t i = 0; i < t->pending.size(); i += VT_TN_MAX_GROUP) {
         const int n = (int)((t->pending.size() - i) < VT_TN_MAX_GROUP ? (t->pending.size() - i) : VT_TN_MAX_GROUP);
@@ -437,9 +463,8 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(vt_gemm_tn_grouped(&w, 1, s));
             TRY(vt_colsum(WS(void, t->dY), 1, Kp, id, t->Mv, Kp, WS(float, t->tmp_vec), WS(void, t->cs_ws), s));
             hipLaunchKernelGGL(scatter_f32_kernel, dim3((Kp + 255) / 256), dim3(256), 0, hs, WS(float, t->tmp_vec), WS(int32_t, t->perm), Kp, G->head_b);
-            (void)hipMemsetAsync(dX, 0, (size_t)t->Mp * D * 4, hs);
-            (void)hipMemsetAsync(WS(void, t->gs[0].dx_out), 0, (size_t)t->Mp * D * 2, hs);
             // rows < Nq of the last decoder block's output are dropped by the slice => zero gradient
+            TRY(vt_zero_rows(dX, WS(void, t->gs[0].dx_out), lmap, t->Mq, D, s));
             TRY(vt_layernorm_bwd(WS(void, t->dhN), WS(float, t->x_dec[c.depth_dec]), vmap, P->head_norm_w, WS(float, t->meanH), WS(float, t->rstdH),
                                  nullptr, t->Mv, D, dX, WS(void, t->gs[0].dx_out), G->head_norm_w, G->head_norm_b,
                                  nullptr, WS(void, t->ln_ws), s));
@@ -461,7 +486,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(vt_gemm_nt(&g, s));
             vtGemmTN w = tn(WS(void, t->dEncb), D, WS(void, t->vq_rzpad), 64, t->Mqp, D, 64, G->out_w, c.d);
             w.q_lim = c.d;
-            TRY(vt_gemm_tn_grouped(&w, 1, s));
+            TRY(skinny_wgrad(t, w, ws, s));
             // VQ backward: straight-through + commitment to z, codebook loss to the embedding
             TRY(vt_vq_backward(WS(float, t->d_rz), 64, gscal, c.beta, c.codebook_w, WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(float, t->vq_E),
                                WS(float, t->vq_wnorm), WS(int64_t, t->vq_idx), t->Mq, c.K, c.d, c.l2_normalized, nullptr, WS(void, t->dz_pad), 64,
@@ -471,10 +496,9 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             (void)hipMemcpyAsync(G->in_b, WS(void, t->tmp_vec), (size_t)c.d * 4, hipMemcpyDeviceToDevice, hs);
             w = tn(WS(void, t->dz_pad), 64, WS(void, t->zb), D, t->Mqp, 64, D, G->in_w, D);
             w.p_lim = c.d;
-            TRY(vt_gemm_tn_grouped(&w, 1, s));
-            (void)hipMemsetAsync(dX, 0, (size_t)t->Mp * D * 4, hs);
+            TRY(skinny_wgrad(t, w, ws, s));
             t->set_idx = 0;
-            (void)hipMemsetAsync(WS(void, t->gs[0].dx_out), 0, (size_t)t->Mp * D * 2, hs);
+            TRY(vt_zero_rows(dX, WS(void, t->gs[0].dx_out), tmap, t->Mv, D, s));  // video-token rows get no gradient from the bottleneck
             g = nt(WS(void, t->dz_pad), 64, WS(void, t->in_wt), 64, t->Mq, D, 64, VT_EPI_F32, dX, D);
             g.out2 = WS(void, t->gs[0].dx_out); g.ldo2 = D; g.omap = qmap;
             TRY(vt_gemm_nt(&g, s));

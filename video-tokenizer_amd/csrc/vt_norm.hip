@@ -190,6 +190,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, 
     }
 }
 
+// zero rows map(r), r < rows, of an fp32 [*, dim] matrix and of its bf16 twin
+__global__ void zero_rows_kernel(float* __restrict__ a, bf16_t* __restrict__ b, RowMap map, int64_t rows, int dim) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows * dim / 4
+    const int d4 = dim >> 2;
+    if (idx >= rows * d4) return;
+    const int64_t pr = map(idx / d4);
+    const int c = (idx % d4) * 4;
+    if (a) *(f32x4*)(a + pr * dim + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (b) *(bf16x4*)(b + pr * dim + c) = (bf16x4){f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+}
+
 // out[j, :] = sum_b src[map(b * n + j), :]   (fp32)
 __global__ void batch_sum_kernel(const float* __restrict__ src, RowMap map, int batch, int n, int dim, float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over n * dim / 4
@@ -330,6 +341,24 @@ extern "C" int vt_colsum(const void* src, int32_t src_is_bf16, int64_t ld, vtRow
     ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32, 1), dim3(256), 0, s, (const float*)workspace, slabs, (int64_t)width, width, ro);
     VT_CHECK_LAUNCH("vt_colsum");
+    return VT_OK;
+}
+
+extern "C" int vt_zero_rows(float* a, void* b_bf16, vtRowMap map, int64_t rows, int32_t dim, vtStream stream) {
+    VT_CHECK_ARG((a || b_bf16) && rows > 0 && dim % 4 == 0, "vt_zero_rows: bad arguments");
+    const int64_t total = rows * (dim / 4);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (bf16_t*)b_bf16, to_map(map), rows, dim);
+    VT_CHECK_LAUNCH("vt_zero_rows");
+    return VT_OK;
+}
+
+// out[c] = sum_s slabs[s * slab_stride + c]  (fixed order; e.g. split-M partial weight gradients)
+extern "C" int vt_sum_slabs(const float* slabs, int32_t nslab, int64_t slab_stride, int32_t width, float* out, vtStream stream) {
+    VT_CHECK_ARG(slabs && out && nslab > 0 && width > 0, "vt_sum_slabs: bad arguments");
+    ReduceOuts ro;
+    ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, slabs, nslab, slab_stride, width, ro);
+    VT_CHECK_LAUNCH("vt_sum_slabs");
     return VT_OK;
 }
 

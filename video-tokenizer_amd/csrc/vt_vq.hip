@@ -300,40 +300,55 @@ __global__ void vq_bwd_tokens_kernel(const float* __restrict__ g_rz, int64_t ldg
     }
 }
 
-// one wave per code: de[k] = sum_{n: idx[n]==k} s_b*2(q-z)/M in ascending n per lane, then a fixed tree;
-// dW[k] = (de - e (e.de)) / |w_k|   (dense gradient, F.embedding sparse=False)
+// Dense codebook gradient, deterministic and atomic-free: de[k] = sum_{n: idx[n]==k} s_b*2(q-z)/M in ascending n
+// per lane, then a fixed tree; dW[k] = (de - e (e.de)) / |w_k|  (F.embedding sparse=False through F.normalize).
+// One workgroup owns CPB consecutive codes (one wave per code at a time) and keeps the whole index vector in LDS
+// as int32, so the N x K membership scan never touches HBM: 16 B per lane per LDS read, 4 indices per compare step.
 template <int DMAX>
 __global__ __launch_bounds__(256) void vq_bwd_codebook_kernel(const float* __restrict__ gscal, float beta, float cbw,
                                                                const float* __restrict__ zn, const float* __restrict__ E,
                                                                const float* __restrict__ wnorm, const int64_t* __restrict__ idx, int N,
-                                                               int K, int d, int normalize, float* __restrict__ dW) {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= K) return;
+                                                               int K, int d, int normalize, int codes_per_block, float* __restrict__ dW) {
+    extern __shared__ __attribute__((aligned(16))) int lds_idx[];  // N rounded up to 256, padded with -1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Np = (N + 255) & ~255;
+    for (int n = threadIdx.x; n < Np; n += 256) lds_idx[n] = n < N ? (int)idx[n] : -1;
+    __syncthreads();
     const float s_b = (gscal ? gscal[0] * cbw + gscal[2] : 0.f) * 2.0f / ((float)N * (float)d);
-    float acc[DMAX];
+    const int k_begin = blockIdx.x * codes_per_block;
+    for (int kk = wave; kk < codes_per_block; kk += 4) {
+        const int k = k_begin + kk;
+        if (k >= K) break;
+        const float* e = E + (int64_t)k * d;
+        float acc[DMAX];
 #pragma unroll
-    for (int j = 0; j < DMAX; ++j) acc[j] = 0.f;
-    const float* e = E + (int64_t)k * d;
-    for (int n = lane; n < N; n += 64) {
-        if (idx[n] == k) {
-            const float* z = zn + (int64_t)n * d;
+        for (int j = 0; j < DMAX; ++j) acc[j] = 0.f;
+        for (int n0 = lane * 4; n0 < Np; n0 += 256) {
+            const int4 v = *(const int4*)(lds_idx + n0);
+            const int hit[4] = {v.x == k, v.y == k, v.z == k, v.w == k};
+            if (hit[0] | hit[1] | hit[2] | hit[3]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (hit[u]) {
+                        const float* z = zn + (int64_t)(n0 + u) * d;
+#pragma unroll
+                        for (int j = 0; j < DMAX; ++j)
+                            if (j < d) acc[j] += e[j] - z[j];
+                    }
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) {
+            acc[j] = wave_sum(acc[j]) * s_b;
+            if (j < d) dot += e[j] * acc[j];
+        }
+        if (lane == 0) {
+            const float inv = 1.0f / wnorm[k];
 #pragma unroll
             for (int j = 0; j < DMAX; ++j)
-                if (j < d) acc[j] += e[j] - z[j];
+                if (j < d) dW[(int64_t)k * d + j] = normalize ? (acc[j] - e[j] * dot) * inv : acc[j];
         }
-    }
-    float dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < DMAX; ++j) {
-        acc[j] = wave_sum(acc[j]) * s_b;
-        if (j < d) dot += e[j] * acc[j];
-    }
-    if (lane == 0) {
-        const float inv = 1.0f / wnorm[k];
-#pragma unroll
-        for (int j = 0; j < DMAX; ++j)
-            if (j < d) dW[(int64_t)k * d + j] = normalize ? (acc[j] - e[j] * dot) * inv : acc[j];
     }
 }
 
@@ -434,10 +449,16 @@ extern "C" int vt_vq_backward(const float* g_rz, int64_t ldg, const float* gscal
     VT_CHECK_ARG(N > 0 && K > 0 && d > 0 && d <= 64, "vt_vq_backward: d=%d out of range", d);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(vq_bwd_tokens_kernel, dim3((N + 255) / 256), dim3(256), 0, s, g_rz, ldg, gscal, beta, codebook_w, zn, znorm, E, idx, N, d, l2_normalized, dz_in, (bf16_t*)dz_pad_bf16, ldp);
-    if (d <= 32)
-        hipLaunchKernelGGL(vq_bwd_codebook_kernel<32>, dim3((K + 3) / 4), dim3(256), 0, s, gscal, beta, codebook_w, zn, E, wnorm, idx, N, K, d, l2_normalized, dW);
-    else
-        hipLaunchKernelGGL(vq_bwd_codebook_kernel<64>, dim3((K + 3) / 4), dim3(256), 0, s, gscal, beta, codebook_w, zn, E, wnorm, idx, N, K, d, l2_normalized, dW);
+    VT_CHECK_ARG(N <= 36864, "vt_vq_backward: N=%d tokens exceed the LDS index staging (36864)", N);
+    const int cpb = 16;  // codes per workgroup: K/16 workgroups (512 at K = 8192)
+    const size_t lds = (size_t)((N + 255) & ~255) * 4;
+    if (d <= 32) {
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)vq_bwd_codebook_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vq_bwd_codebook_kernel<32>, dim3((K + cpb - 1) / cpb), dim3(256), lds, s, gscal, beta, codebook_w, zn, E, wnorm, idx, N, K, d, l2_normalized, cpb, dW);
+    } else {
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)vq_bwd_codebook_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vq_bwd_codebook_kernel<64>, dim3((K + cpb - 1) / cpb), dim3(256), lds, s, gscal, beta, codebook_w, zn, E, wnorm, idx, N, K, d, l2_normalized, cpb, dW);
+    }
     VT_CHECK_LAUNCH("vt_vq_backward");
     return VT_OK;
 }

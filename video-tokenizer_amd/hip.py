@@ -49,6 +49,8 @@ SIGNATURES = {
     "vt_colsum": (c_i32, [c_vp, c_i32, c_i64, RowMap, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "vt_batch_sum": (c_i32, [c_vp, RowMap, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vt_cast_rows": (c_i32, [c_vp, RowMap, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "vt_zero_rows": (c_i32, [c_vp, c_vp, RowMap, c_i64, c_i32, c_vp]),
+    "vt_sum_slabs": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "vt_assemble_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "vt_patchify": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
