@@ -120,7 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="B")
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
-    ap.add_argument("--optimizer", action="store_true", help="also run torch.optim.Adam inside the step")
+    ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
+                    help="also step Adam(lr 1e-4, betas (0.5,0.9)) inside the timed step: 'fused' = vt_adam_step over flat buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -146,7 +147,13 @@ def main():
         torch.nn.init.xavier_uniform_(model.final_layer.linear.weight)
     model = model.to(dev).train()
     net = DataParallelTokenizer(model) if world > 1 else model
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.5, 0.9)) if a.optimizer else None
+    if a.optimizer == "torch":
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    elif a.optimizer == "fused":
+        from video_tokenizer_amd.optim import FusedAdam
+        opt = FusedAdam(model, lr=1e-4, betas=(0.5, 0.9))
+    else:
+        opt = None
 
     B = a.batch
     x = torch.from_numpy(gen.video_clips(B, c["frame_num"], c["input_size"], 100 + rank)).to(dev)
@@ -194,7 +201,7 @@ def main():
             "config": {"workload": f"cfgs/larp_tokenizer.yaml base geometry as LARPTokenizer(bottleneck_type=vq): config {a.config}, "
                                    f"{c['frame_num']}x{c['input_size']}x{c['input_size']} clips, {B} clips/GPU, "
                                    f"{c['encoder_depth']}+{c['decoder_depth']} blocks, Nq={c['bottleneck_token_num']}, d={c['bottleneck_dim']}, K={c['codebook_size']}, "
-                                   f"stochastic VQ (tau 0.03), loss = L1 + 0.1*loss_q" + (", Adam" if opt else ""),
+                                   f"stochastic VQ (tau 0.03), loss = L1 + 0.1*loss_q" + (f", Adam ({a.optimizer})" if opt else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "model_tflops_per_gpu": round(clips_s / world * f_clip / 1e12, 1),
             "attention_gemm_tflops_per_gpu": round(clips_s / world * f_attn / 1e12, 1),

@@ -195,6 +195,15 @@ int vt_vq_gather(const float* E, const int64_t* idx, int32_t N, int32_t K, int32
 
 
 /* ------------------------------------------------------------------------------------------
+ * Fused Adam (+ optional EMA) over flat fp32 buffers: replaces optimizer.step() of torch.optim.Adam
+ * (trainers/larp_tokenizer_trainer.py:160-212 builds Adam(lr, betas); :376-377 steps it) and
+ * update_ema (trainers/base_trainer.py:769-779), one HBM-bound pass.  n % 4 == 0; step counts from 1;
+ * ema may be NULL.  torch.optim.Adam semantics (L2 weight decay, no amsgrad).
+ * ------------------------------------------------------------------------------------------ */
+int vt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, float* ema, float ema_decay, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole-model engine: LARPTokenizer.forward = encode -> bottleneck(VQ) -> decode
  * (models/larp_tokenizer.py:400-428, 456-469, 489-496; TransformerEncoderParallel.forward
  * models/transformer.py:62-70; Bottleneck.forward models/bottleneck.py:170-188) and the backward

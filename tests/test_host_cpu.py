@@ -187,3 +187,30 @@ def test_engine_plan_sizes_host_only():
     assert 8e9 < nbytes < 20e9, nbytes
     assert lib.vt_tokenizer_num_backward_stages(h) == 27
     lib.vt_tokenizer_destroy(h)
+
+
+def test_frechet_distance_and_feature_stats():
+    """metrics.py against scipy's matrix square root on synthetic Gaussian features (the I3D extractor is absent)."""
+    import scipy.linalg
+    from video_tokenizer_amd.metrics import FeatureStats, clip_mse, frechet_distance, psnr_given_mse
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(2000, 24)).astype(np.float32) @ rng.normal(size=(24, 24)).astype(np.float32)
+    Bf = rng.normal(size=(1500, 24)).astype(np.float32) * 1.3 + 0.2
+    sa, sb = FeatureStats(), FeatureStats(max_items=1200)
+    for chunk in np.array_split(A, 7):
+        sa.append(chunk)
+    for chunk in np.array_split(Bf, 5):
+        sb.append(torch.from_numpy(chunk))
+    assert sb.num_items == 1200 and sb.is_full()
+    mu_a, cov_a = sa.get_mean_cov()
+    np.testing.assert_allclose(mu_a, A.astype(np.float64).mean(0), rtol=1e-10)
+    np.testing.assert_allclose(cov_a, np.cov(A.astype(np.float64), rowvar=False, bias=True), rtol=1e-8, atol=1e-8)
+    mu_b, cov_b = sb.get_mean_cov()
+    covmean = scipy.linalg.sqrtm(cov_a @ cov_b).real
+    want = ((mu_a - mu_b) ** 2).sum() + np.trace(cov_a) + np.trace(cov_b) - 2 * np.trace(covmean)
+    np.testing.assert_allclose(frechet_distance(sa, sb), want, rtol=1e-6)
+    assert abs(frechet_distance(sa, sa)) < 1e-6 * np.trace(cov_a)
+    v = torch.rand(3, 3, 4, 8, 8)
+    r = v + 0.1
+    mse = clip_mse(v, r)
+    assert mse.shape == (3,) and abs(psnr_given_mse(torch.full((3,), 0.01)) - 20.0) < 1e-5

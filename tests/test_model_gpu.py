@@ -154,7 +154,7 @@ def test_data_parallel_wrapper_single_rank_rccl():
         dp = DataParallelTokenizer(model, bucket_bytes=8 << 20)
         red = model._engine.reducer
         wrapped = run(dp)
-        assert red.launched and red.launched[0][0] == 0 and red.launched[-1][1] == model._engine.flat_grad.numel()
+        assert red.launched and red.launched[0][0] == 0 and red.launched[-1][1] == sum(p.numel() for p in model.parameters())
         assert all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:])) and len(red.launched) >= 3
         for n in plain:
             assert torch.equal(plain[n], wrapped[n]), n
@@ -227,3 +227,70 @@ def test_f256_geometries_size_independent_properties(name):
     # argmax really is the best code: no other code has a larger cosine (checked densely for 64 tokens)
     cos = uz.reshape(-1, emb.shape[1])[:64] @ emb.t()
     assert torch.equal(cos.argmax(dim=-1), a["bottleneck_rep"].reshape(-1)[:64])
+
+
+def test_adam_kernel_matches_torch_adam():
+    """vt_adam_step == torch.optim.Adam on identical gradients, 5 steps, with weight decay and fused EMA."""
+    import video_tokenizer_amd.hip as hip
+    g = torch.Generator().manual_seed(0)
+    n = 4 * 100003
+    p0 = torch.randn(n, generator=g)
+    p = p0.clone().cuda()
+    m, v, ema = torch.zeros(n).cuda(), torch.zeros(n).cuda(), p0.clone().cuda()
+    ref = torch.nn.Parameter(p0.clone().cuda())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.5, 0.9), eps=1e-8, weight_decay=0.01)
+    ema_ref = p0.clone().cuda()
+    for step in range(1, 6):
+        grad = (torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g)))).cuda()
+        hip.check(hip.lib().vt_adam_step(hip.ptr(p), hip.ptr(grad), hip.ptr(m), hip.ptr(v), n, 1e-3, 0.5, 0.9, 1e-8, 0.01, step,
+                                         hip.ptr(ema), 0.99, hip.stream()))
+        ref.grad = grad.clone()
+        opt.step()
+        ema_ref.mul_(0.99).add_(ref.data, alpha=0.01)
+    torch.cuda.synchronize()
+    assert rel(p.cpu(), ref.detach().cpu()) < 1e-6
+    assert rel(ema.cpu(), ema_ref.cpu()) < 1e-6
+    st = opt.state[ref]
+    assert rel(m.cpu(), st["exp_avg"].cpu()) < 1e-6 and rel(v.cpu(), st["exp_avg_sq"].cpu()) < 1e-6
+
+
+def test_fused_adam_on_the_model():
+    """FusedAdam over the flattened tokenizer parameters: first step equals torch.optim.Adam parameter by parameter
+    (identical gradients), training continues through re-packed weights, optimizer state round-trips."""
+    from video_tokenizer_amd.optim import FusedAdam, flatten_parameters
+    cfg = O.make_cfg("tiny")
+    model, sd = build(cfg)
+    ref_model, _ = build(cfg)
+    x = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 61)).cuda()
+    opt = FusedAdam(model, lr=1e-3, betas=(0.5, 0.9), ema_decay=0.9)
+    ref_opt = torch.optim.Adam(ref_model.parameters(), lr=1e-3, betas=(0.5, 0.9))
+    losses = []
+    for it in range(3):
+        for net, o in ((model, opt), (ref_model, ref_opt)):
+            o.zero_grad(set_to_none=True)
+            out = net(x)
+            loss = (out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_q"]
+            loss.backward()
+            if it == 0 and net is ref_model:  # identical weights => identical kernels => identical gradients
+                for (n, a), (_, b) in zip(model.named_parameters(), ref_model.named_parameters()):
+                    assert torch.equal(a.grad, b.grad), n
+            o.step()
+            if net is model:
+                losses.append(loss.item())
+        if it == 0:
+            torch.cuda.synchronize()
+            ref_params = dict(ref_model.named_parameters())
+            for n, p in model.named_parameters():
+                assert rel(p.detach().cpu(), ref_params[n].detach().cpu()) < 1e-6, n
+    torch.cuda.synchronize()
+    assert losses[2] < losses[0]  # it trains
+    flat = flatten_parameters(model)
+    assert flat.data_ptr() <= next(model.parameters()).data_ptr() < flat.data_ptr() + flat.numel() * 4
+    ema = opt.ema_state_dict()
+    assert set(ema.keys()) == set(sd.keys())
+    sd_opt = opt.state_dict()
+    assert len(sd_opt["state"]) == len(list(model.parameters())) and sd_opt["param_groups"][0]["betas"] == (0.5, 0.9)
+    opt2 = FusedAdam(model, lr=1e-3, betas=(0.5, 0.9))
+    opt2.load_state_dict(sd_opt)
+    assert opt2.step_count == 3 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    assert set(model.state_dict().keys()) == set(sd.keys())  # flat re-pointing keeps the checkpoint layout

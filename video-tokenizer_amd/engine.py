@@ -158,7 +158,7 @@ class TokenizerEngine:
             segs[st] = (lo, off + n)
             off += n
         total = off
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total + ((-total) % 4), dtype=torch.float32, device=device)  # padded like the flat parameter buffer
         off, offsets = 0, {}
         for name, p, st in self.order:
             views[name] = self.flat_grad[off:off + p.numel()].view(p.shape)
@@ -170,7 +170,8 @@ class TokenizerEngine:
         self.grad_struct = _Tensors(self.model, lambda n: views[n].data_ptr() if n in views else None)
 
     def params_version(self):
-        return sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.model.buffers())
+        return (sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.model.buffers()),
+                getattr(self, "param_epoch", 0), getattr(self, "flat_param", None) is not None)
 
     # ------------------------------------------------------------------ states
     def state_for(self, B, T, S, device):

@@ -64,6 +64,7 @@ SIGNATURES = {
                                c_vp, c_vp, c_i64, c_vp, c_vp]),
     "vt_vq_prep_codebook": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_vq_gather": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "vt_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp]),
 }
 
 
