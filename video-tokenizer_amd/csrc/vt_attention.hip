@@ -153,17 +153,21 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
 // forward
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
-                                                           int L, int H, float scale_log2e) {
+                                                           int L, int H, int nblk, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    // 1-D grid, XCD-aware: the nblk row-blocks of one (batch, head) get consecutive ids inside ONE XCD's chunk, so the
+    // K/V tiles they all stream are fetched into that XCD's L2 once instead of once per XCD
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = sid / nblk, blk = sid - bh * nblk;
+    const int b = bh / H, h = bh % H;
     const int64_t rs = (int64_t)3 * H * HD;
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
     const bf16_t* vb = kb + (int64_t)H * HD;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk * 128 + wave * 32;
 
     bf16x8 qf[4];
     load_own(qb, rs, q0, L, lane, qf);
@@ -261,17 +265,19 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale, float scale_log2e) {
+                                                              bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);  // see attn_fwd_kernel
+    const int bh = sid / nblk, blk = sid - bh * nblk;
+    const int b = bh / H, h = bh % H;
     const int64_t rs = (int64_t)3 * H * HD, ors = (int64_t)H * HD;
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
     const bf16_t* vb = kb + (int64_t)H * HD;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk * 128 + wave * 32;
     const int q = q0 + (lane & 31);
     const int qc = q < L ? q : L - 1;
 
@@ -361,12 +367,14 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[4]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale, float scale_log2e) {
+                                                               bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);  // key blocks of one head share the Q/dO stream: keep them on one XCD
+    const int bh = sid / nblk, blk = sid - bh * nblk;
+    const int b = bh / H, h = bh % H;
     const int64_t rs = (int64_t)3 * H * HD, ors = (int64_t)H * HD;
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const bf16_t* dob = dO + (int64_t)b * L * ors + (int64_t)h * HD;
     const float* lse_b = lse2 + ((int64_t)b * H + h) * L;
     const float* del_b = delta + ((int64_t)b * H + h) * L;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = blk * 128 + wave * 32;
     const int key = k0 + (lane & 31);
 
     bf16x8 kf[4], vf[4];
@@ -424,7 +432,8 @@ extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H
     VT_CHECK_ARG(hd == 64, "vt_attention_fwd: head_dim %d unsupported (64 only)", hd);
     VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_fwd: bad shape");
     const float sl2 = 0.125f * 1.44269504088896340736f;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((L + 127) / 128, B * H), dim3(256), 4 * TILE, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, sl2);
+    const int nblk = (L + 127) / 128;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * B * H), dim3(256), 4 * TILE, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2);
     VT_CHECK_LAUNCH("vt_attention_fwd");
     return VT_OK;
 }
@@ -438,9 +447,10 @@ extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, 
     const float scale = 0.125f, sl2 = 0.125f * 1.44269504088896340736f;
     const int64_t BL = (int64_t)B * L;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((BL * H + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o, (const bf16_t*)dO, delta_ws, BL, L, H);
-    const dim3 grid((L + 127) / 128, B * H);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * TILE, s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, scale, sl2);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * (2 * TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, scale, sl2);
+    const int nblk = (L + 127) / 128;
+    const dim3 grid(nblk * B * H);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * TILE, s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * (2 * TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
     VT_CHECK_LAUNCH("vt_attention_bwd");
     return VT_OK;
 }
