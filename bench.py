@@ -178,8 +178,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = []
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host.append(time.perf_counter() - h0)  # host-side enqueue time of the step (no sync inside)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,6 +206,7 @@ def main():
                                    f"{c['encoder_depth']}+{c['decoder_depth']} blocks, Nq={c['bottleneck_token_num']}, d={c['bottleneck_dim']}, K={c['codebook_size']}, "
                                    f"stochastic VQ (tau 0.03), loss = L1 + 0.1*loss_q" + (f", Adam ({a.optimizer})" if opt else ""),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
+            "host_enqueue_ms_per_step": round(sorted(host)[len(host) // 2] * 1e3, 3),
             "model_tflops_per_gpu": round(clips_s / world * f_clip / 1e12, 1),
             "attention_gemm_tflops_per_gpu": round(clips_s / world * f_attn / 1e12, 1),
         }

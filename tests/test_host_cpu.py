@@ -214,3 +214,20 @@ def test_frechet_distance_and_feature_stats():
     r = v + 0.1
     mse = clip_mse(v, r)
     assert mse.shape == (3,) and abs(psnr_given_mse(torch.full((3,), 0.01)) - 20.0) < 1e-5
+
+
+def test_model_deepcopy_and_requires_grad_helpers():
+    """the reference trainer deep-copies the model for EMA and toggles requires_grad on parameter groups"""
+    import copy
+    cfg = O.make_cfg("tiny")
+    m = vt.make(spec_from_cfg(cfg))
+    c = copy.deepcopy(m)
+    assert c._engine is not m._engine and c._engine.model is c
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    c.requires_grad_(False)
+    assert all(not p.requires_grad for p in c.parameters()) and all(p.requires_grad for p in m.parameters())
+    m.decoder_requires_grad_(False)
+    dec = set(id(p) for p in m.decoder_parameters())
+    assert all(p.requires_grad == (id(p) not in dec) for p in m.parameters())
+    m.others_requires_grad_(False)
+    assert not any(p.requires_grad for p in m.parameters())

@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["vt_api.cpp", "vt_gemm.hip", "vt_gemm192.hip", "vt_norm.hip", "vt_patch.hip", "vt_vq.hip", "vt_attention.hip", "vt_optim.hip", "vt_engine.hip"]
+AUDIT_NO_SPILL = {"vt_gemm192.hip", "vt_attention.hip"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -32,17 +33,29 @@ def build(force=False, verbose=False):
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(d, op) for d in deps):
             cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            if src in AUDIT_NO_SPILL:
+                cmd.append("-Rpass-analysis=kernel-resource-usage")
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
+        text = out.decode()
         if p.returncode != 0:
             failed = True
-            sys.stderr.write(f"--- {src} failed ---\n{out.decode()}\n")
-        elif verbose and out:
-            sys.stderr.write(out.decode())
+            sys.stderr.write(f"--- {src} failed ---\n{text}\n")
+            continue
+        if src in AUDIT_NO_SPILL:
+            # these kernels load LDS fragments / issue LDS-DMA through inline asm; a register spill would move an
+            # asm destination before its data has landed (silent wrong results), so spills are a build error
+            bad = [ln for ln in text.splitlines() if ("Spill:" in ln or "ScratchSize" in ln) and not ln.rstrip().split()[-2].strip(":") == "0"
+                   and not ln.rstrip().endswith(" 0 [-Rpass-analysis=kernel-resource-usage]")]
+            if bad:
+                failed = True
+                sys.stderr.write(f"--- {src}: register spills / scratch in an inline-asm kernel ---\n" + "\n".join(bad[:8]) + "\n")
+        elif verbose and text:
+            sys.stderr.write(text)
     if failed:
         raise RuntimeError("hipcc failed")
     if force or procs or not os.path.exists(LIB):

@@ -34,6 +34,7 @@ __device__ __forceinline__ void raw_barrier() {
 struct NT192Args {
     vtGemmNT p;
     int tiles_m, tiles_n;
+    int dbg;  // timing experiments only (vt_set_gemm_variant 3/4): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads
 };
 
 __device__ __forceinline__ void stage_nt192(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0, unsigned lds, int tid, int wave) {
@@ -46,6 +47,20 @@ __device__ __forceinline__ void stage_nt192(const bf16_t* __restrict__ g, int64_
         gr = gr < nrows ? gr : nrows - 1;
         glds16_asm(g + (int64_t)gr * ld + k0 + lc * 8, lds + (i * 512 + wave * 64) * 16);
     }
+}
+
+// one of the six 16-B-per-lane DMA pieces of a K-tile: pieces 0..2 = A rows, 3..5 = B rows
+__device__ __forceinline__ void stage_piece_nt192(const bf16_t* __restrict__ A, int64_t lda, int m0, int M, const bf16_t* __restrict__ B,
+                                                  int64_t ldb, int n0, int N, int k0, unsigned lds, int piece, int tid, int wave) {
+    const int i = piece < 3 ? piece : piece - 3;
+    const int slot = i * 512 + tid;
+    const int row = slot >> 3;
+    const int lc = (slot & 7) ^ ((row >> 1) & 7);
+    int gr = (piece < 3 ? m0 : n0) + row;
+    const int lim = piece < 3 ? M : N;
+    gr = gr < lim ? gr : lim - 1;
+    const bf16_t* g = piece < 3 ? A + (int64_t)gr * lda : B + (int64_t)gr * ldb;
+    glds16_asm(g + k0 + lc * 8, lds + (piece < 3 ? 0 : OP_BYTES) + (i * 512 + wave * 64) * 16);
 }
 
 __device__ __forceinline__ bf16x8 frag_nt192(const char* lds, int row, int lchunk) {
@@ -75,71 +90,126 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
 
     const int nt = p.K / TK;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    stage_nt192(A, p.lda, m0, p.M, 0, sbase, tid, wave);
-    stage_nt192(B, p.ldb, n0, p.N, 0, sbase + OP_BYTES, tid, wave);
-    if (nt > 1) {
-        stage_nt192(A, p.lda, m0, p.M, TK, sbase + STAGE_BYTES, tid, wave);
-        stage_nt192(B, p.ldb, n0, p.N, TK, sbase + STAGE_BYTES + OP_BYTES, tid, wave);
-    }
     const int fr = lane & 15, fq = lane >> 4;
     // byte offset of this lane's first A / B fragment inside an operand tile, for k-step 0 and 1.  The swizzle term
     // ((row>>1)&7) does not depend on the 16-row fragment index (16 rows = 8 swizzle periods), so fragment i sits at
     // +i*2048 bytes: an instruction immediate.
     const int arow = wm * 96 + fr, brow = wn * 48 + fr;
     const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4), a_off1 = arow * 128 + (((4 + fq) ^ ((arow >> 1) & 7)) << 4);
-    const unsigned b_off0 = brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4), b_off1 = brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4);
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) wait_vmcnt6(); else wait_vmcnt0();  // this thread's pieces of tile t have landed
-        raw_barrier();                                        // everyone's have; everyone is done reading tile t-1
-        if (t + 2 < nt) {
-            int nx = cur + 2; nx = nx >= NSTAGE ? nx - NSTAGE : nx;
-            stage_nt192(A, p.lda, m0, p.M, (t + 2) * TK, sbase + nx * STAGE_BYTES, tid, wave);
-            stage_nt192(B, p.ldb, n0, p.N, (t + 2) * TK, sbase + nx * STAGE_BYTES + OP_BYTES, tid, wave);
-        }
-        // Fragment reads are hand-issued (inline asm) so that the LDS waits can be COUNTED: hipcc emits lgkmcnt(0)
-        // for ds_read_b128 fragments in this loop.  LDS returns in order, so after issuing reads r0..r13 a
-        // wait lgkmcnt(13 - k) means r0..rk have landed.  Each wait is followed by sched_barrier(0) so no MFMA is
-        // hoisted above it.  Order: b0[0..2] a0[0..5] | b1[0..2] a1[0..1]   (14 in flight: 4-bit counter)
-        const unsigned ta = sbase + cur * STAGE_BYTES;
-        const unsigned a_k0 = ta + a_off0, a_k1 = ta + a_off1, b_k0 = ta + OP_BYTES + b_off0, b_k1 = ta + OP_BYTES + b_off1;
-        bf16x8 a0[6], b0[3], a1[6], b1[3];
+    const unsigned b_off0 = OP_BYTES + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
+    const unsigned b_off1 = OP_BYTES + brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4);
+
+    // ---- software pipeline across K-tiles -------------------------------------------------------------------------
+    // Tile t is multiplied out of a REGISTER set while the 18 fragment reads of tile t+1 are issued between its MFMA
+    // rows into the other set, and the LDS-DMA of tile t+3 is in flight into the LDS buffer tile t just vacated.
+    // (Without this, all 8 waves burst-read 144 KB of fragments after every barrier before any MFMA can issue: an
+    // ablation with the DMA removed still ran at 88 % of the full kernel's time.)  Reads and DMAs are inline asm, so
+    // every wait is explicit: vmcnt counts this thread's 6 DMA pieces per tile, lgkmcnt(0) closes a tile's reads
+    // before the barrier that lets other waves overwrite that LDS buffer.
 #define VT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define VT_LGKM(n)                                            \
-    __builtin_amdgcn_sched_barrier(0);                        \
-    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");   \
-    __builtin_amdgcn_sched_barrier(0)
 #define VT_ROW(accrow, bb, aa)                                                                   \
     accrow[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[0], aa, accrow[0], 0, 0, 0);          \
     accrow[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[1], aa, accrow[1], 0, 0, 0);          \
-    accrow[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[2], aa, accrow[2], 0, 0, 0)
-        VT_DSR(b0[0], b_k0, 0); VT_DSR(b0[1], b_k0, 2048); VT_DSR(b0[2], b_k0, 4096);
-        VT_DSR(a0[0], a_k0, 0); VT_DSR(a0[1], a_k0, 2048); VT_DSR(a0[2], a_k0, 4096);
-        VT_DSR(a0[3], a_k0, 6144); VT_DSR(a0[4], a_k0, 8192); VT_DSR(a0[5], a_k0, 10240);
-        VT_DSR(b1[0], b_k1, 0); VT_DSR(b1[1], b_k1, 2048); VT_DSR(b1[2], b_k1, 4096);
-        VT_DSR(a1[0], a_k1, 0); VT_DSR(a1[1], a_k1, 2048);
-        VT_LGKM(10); VT_ROW(acc[0], b0, a0[0]);
-        VT_LGKM(9);  VT_ROW(acc[1], b0, a0[1]);
-        VT_LGKM(8);  VT_ROW(acc[2], b0, a0[2]);
-        VT_LGKM(7);  VT_ROW(acc[3], b0, a0[3]);
-        __builtin_amdgcn_sched_barrier(0);
-        VT_DSR(a1[2], a_k1, 4096); VT_DSR(a1[3], a_k1, 6144);           // 6 + 2 in flight
-        VT_LGKM(7);  VT_ROW(acc[4], b0, a0[4]);
-        VT_LGKM(6);  VT_ROW(acc[5], b0, a0[5]);
-        __builtin_amdgcn_sched_barrier(0);
-        VT_DSR(a1[4], a_k1, 8192); VT_DSR(a1[5], a_k1, 10240);          // b1 x3, a1[0..3], + 2 = 9 in flight
-        VT_LGKM(5);  VT_ROW(acc[0], b1, a1[0]);
-        VT_LGKM(4);  VT_ROW(acc[1], b1, a1[1]);
-        VT_LGKM(3);  VT_ROW(acc[2], b1, a1[2]);
-        VT_LGKM(2);  VT_ROW(acc[3], b1, a1[3]);
-        VT_LGKM(1);  VT_ROW(acc[4], b1, a1[4]);
-        VT_LGKM(0);  VT_ROW(acc[5], b1, a1[5]);
-        __builtin_amdgcn_sched_barrier(0);
-#undef VT_DSR
-#undef VT_LGKM
-#undef VT_ROW
-        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    accrow[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[2], aa, accrow[2], 0, 0, 0);          \
+    __builtin_amdgcn_sched_barrier(0)
+    // compute from set C (a0,b0 = k-step 0; a1,b1 = k-step 1) while prefetching the tile at LDS address `nb` into set N
+#define VT_DMA(k) if (dma_tile >= 0) stage_piece_nt192(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, dma_tile * TK, dma_dst, k, tid, wave)
+#define VT_STEP(Ca0, Cb0, Ca1, Cb1, Na0, Nb0, Na1, Nb1, nb, pf)                                                      \
+    {                                                                                                                \
+        const unsigned na0 = (nb) + a_off0, na1 = (nb) + a_off1, nb0 = (nb) + b_off0, nb1 = (nb) + b_off1;           \
+        if (pf) { VT_DSR(Nb0[0], nb0, 0); VT_DSR(Nb0[1], nb0, 2048); }                                               \
+        VT_ROW(acc[0], Cb0, Ca0[0]);                                                                                 \
+        VT_DMA(0);                                                                                                   \
+        if (pf) { VT_DSR(Nb0[2], nb0, 4096); VT_DSR(Na0[0], na0, 0); }                                               \
+        VT_ROW(acc[1], Cb0, Ca0[1]);                                                                                 \
+        VT_DMA(1);                                                                                                   \
+        if (pf) { VT_DSR(Na0[1], na0, 2048); VT_DSR(Na0[2], na0, 4096); }                                            \
+        VT_ROW(acc[2], Cb0, Ca0[2]);                                                                                 \
+        VT_DMA(2);                                                                                                   \
+        if (pf) { VT_DSR(Na0[3], na0, 6144); VT_DSR(Na0[4], na0, 8192); }                                            \
+        VT_ROW(acc[3], Cb0, Ca0[3]);                                                                                 \
+        VT_DMA(3);                                                                                                   \
+        if (pf) { VT_DSR(Na0[5], na0, 10240); VT_DSR(Nb1[0], nb1, 0); }                                              \
+        VT_ROW(acc[4], Cb0, Ca0[4]);                                                                                 \
+        VT_DMA(4);                                                                                                   \
+        if (pf) { VT_DSR(Nb1[1], nb1, 2048); VT_DSR(Nb1[2], nb1, 4096); }                                            \
+        VT_ROW(acc[5], Cb0, Ca0[5]);                                                                                 \
+        VT_DMA(5);                                                                                                   \
+        if (pf) { VT_DSR(Na1[0], na1, 0); }                                                                          \
+        VT_ROW(acc[0], Cb1, Ca1[0]);                                                                                 \
+        if (pf) { VT_DSR(Na1[1], na1, 2048); }                                                                       \
+        VT_ROW(acc[1], Cb1, Ca1[1]);                                                                                 \
+        if (pf) { VT_DSR(Na1[2], na1, 4096); }                                                                       \
+        VT_ROW(acc[2], Cb1, Ca1[2]);                                                                                 \
+        if (pf) { VT_DSR(Na1[3], na1, 6144); }                                                                       \
+        VT_ROW(acc[3], Cb1, Ca1[3]);                                                                                 \
+        if (pf) { VT_DSR(Na1[4], na1, 8192); }                                                                       \
+        VT_ROW(acc[4], Cb1, Ca1[4]);                                                                                 \
+        if (pf) { VT_DSR(Na1[5], na1, 10240); }                                                                      \
+        VT_ROW(acc[5], Cb1, Ca1[5]);                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
+    auto issue_tile = [&](int tile) {  // LDS-DMA of K-tile `tile` into ring buffer tile % 3
+        const unsigned dst = sbase + (tile % NSTAGE) * STAGE_BYTES;
+        stage_nt192(A, p.lda, m0, p.M, tile * TK, dst, tid, wave);
+        stage_nt192(B, p.ldb, n0, p.N, tile * TK, dst + OP_BYTES, tid, wave);
+    };
+    // make tile `nx` visible to every wave (its DMA landed everywhere) and recycle the buffer of tile nx-1, whose
+    // fragments every wave already holds in registers, for tile nx+2
+    // The 6 DMA pieces of tile nx+2 are issued between the first MFMA rows of the following tile body (VT_DMA), so the
+    // matrix pipe restarts right behind the barrier instead of behind ~150 cycles of DMA issue.
+    auto sync_for = [&](int nx) {
+        if (nx + 1 < nt) wait_vmcnt6(); else wait_vmcnt0();
+        raw_barrier();
+    };
+
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
+    if (nt > 2) issue_tile(2);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nt > 1) wait_vmcnt6();
+    else wait_vmcnt0();
+    raw_barrier();
+    bf16x8 xa0[6], xb0[3], xa1[6], xb1[3], ya0[6], yb0[3], ya1[6], yb1[3];
+    {   // fragments of tile 0
+        const unsigned na0 = sbase + a_off0, na1 = sbase + a_off1, nb0 = sbase + b_off0, nb1 = sbase + b_off1;
+        VT_DSR(xb0[0], nb0, 0); VT_DSR(xb0[1], nb0, 2048); VT_DSR(xb0[2], nb0, 4096);
+        VT_DSR(xa0[0], na0, 0); VT_DSR(xa0[1], na0, 2048); VT_DSR(xa0[2], na0, 4096);
+        VT_DSR(xa0[3], na0, 6144); VT_DSR(xa0[4], na0, 8192); VT_DSR(xa0[5], na0, 10240);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        VT_DSR(xb1[0], nb1, 0); VT_DSR(xb1[1], nb1, 2048); VT_DSR(xb1[2], nb1, 4096);
+        VT_DSR(xa1[0], na1, 0); VT_DSR(xa1[1], na1, 2048); VT_DSR(xa1[2], na1, 4096);
+        VT_DSR(xa1[3], na1, 6144); VT_DSR(xa1[4], na1, 8192); VT_DSR(xa1[5], na1, 10240);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int t = 0;;) {
+        // tile t from set X, prefetch tile t+1 into set Y.  The prefetch is unconditional (branch-free tile body, one
+        // body per register set): after the last tile it re-reads a valid, quiescent LDS buffer into the unused set.
+        {
+            const bool more = t + 1 < nt;
+            if (more) sync_for(t + 1);
+            const unsigned nb = sbase + ((more ? t + 1 : t) % NSTAGE) * STAGE_BYTES;
+            const int dma_tile = (t + 3 < nt && a.dbg != 1) ? t + 3 : -1;  // goes into the buffer tile t just vacated
+            const unsigned dma_dst = sbase + (t % NSTAGE) * STAGE_BYTES;
+            if (a.dbg != 2) VT_STEP(xa0, xb0, xa1, xb1, ya0, yb0, ya1, yb1, nb, true)
+            if (++t == nt) break;
+        }
+        {   // tile t from set Y, prefetch tile t+1 into set X
+            const bool more = t + 1 < nt;
+            if (more) sync_for(t + 1);
+            const unsigned nb = sbase + ((more ? t + 1 : t) % NSTAGE) * STAGE_BYTES;
+            const int dma_tile = (t + 3 < nt && a.dbg != 1) ? t + 3 : -1;
+            const unsigned dma_dst = sbase + (t % NSTAGE) * STAGE_BYTES;
+            if (a.dbg != 2) VT_STEP(ya0, yb0, ya1, yb1, xa0, xb0, xa1, xb1, nb, true)
+            if (++t == nt) break;
+        }
+    }
+#undef VT_DSR
+#undef VT_ROW
+#undef VT_STEP
+#undef VT_DMA
 
     const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
 #pragma unroll
@@ -294,9 +364,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
 }  // namespace
 
 // Called by vt_gemm_nt / vt_gemm_tn_grouped (vt_gemm.hip) after argument validation.
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s) {
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg) {
     NT192Args a;
     a.p = p;
+    a.dbg = dbg;
     a.tiles_m = (p.M + TM - 1) / TM;
     a.tiles_n = (p.N + TN_ - 1) / TN_;
     const dim3 grid(a.tiles_m * a.tiles_n), block(512);

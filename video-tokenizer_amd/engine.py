@@ -126,6 +126,19 @@ class TokenizerEngine:
         self.reducer = None   # set by parallel.DataParallelTokenizer
         self.seed_counter = 0
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) (the reference trainer builds its EMA model that way, base_trainer.py:396-405) must not
+        copy native handles or workspaces: the copy gets a fresh, empty engine bound to the copied module."""
+        new = TokenizerEngine(memo.get(id(self.model), self.model))
+        memo[id(self)] = new
+        return new
+
+    def __getstate__(self):  # torch.save(model) / pickling: drop native state
+        return {"model": self.model}
+
+    def __setstate__(self, st):
+        self.__init__(st["model"])
+
     # ------------------------------------------------------------------ parameters / gradients
     def _named(self):
         m = self.model
