@@ -195,13 +195,13 @@ def test_config_A_full_depth_matches_oracle():
     assert all(e < 8e-2 for _, e in bad), bad
 
 
-@pytest.mark.parametrize("name", ["C", "D"])
+@pytest.mark.parametrize("name", ["C", "D", "E"])
 def test_f256_geometries_size_independent_properties(name):
-    """BASELINE configs[2], [3] (pt4 p8, 6+6 blocks, d=16, 512 / 1024 latent tokens) at full 16x128x128 size, where the
-    CPU oracle is too slow: properties that hold at any size."""
+    """BASELINE configs[2], [3] (pt4 p8, 6+6 blocks, d=16, 512 / 1024 latent tokens, 16x128x128) and [4] (16x256x256:
+    L = 5120) at full size, where the CPU oracle is too slow: properties that hold at any size."""
     cfg = O.make_cfg(name)
     model, sd = build(cfg, seed=5, stochastic=True)
-    x = torch.from_numpy(gen.video_clips(2, 16, 128, 51)).cuda()
+    x = torch.from_numpy(gen.video_clips(2, 16, cfg["input_size"], 51)).cuda()
     model.eval()
     model.set_vq_eval_deterministic(True)
     with torch.no_grad():
