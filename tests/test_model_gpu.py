@@ -294,3 +294,30 @@ def test_fused_adam_on_the_model():
     opt2.load_state_dict(sd_opt)
     assert opt2.step_count == 3 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
     assert set(model.state_dict().keys()) == set(sd.keys())  # flat re-pointing keeps the checkpoint layout
+
+
+def test_forward_is_hipgraph_capturable():
+    """The engine enqueues the whole forward without allocating or synchronising: capture encode+decode into a HIP
+    graph (torch.cuda.CUDAGraph), replay it on new input data, and compare with the eager result bit for bit."""
+    cfg = O.make_cfg("tiny")
+    model, _ = build(cfg, stochastic=True)
+    model.eval()
+    model.set_vq_eval_deterministic(True)
+    x_static = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 71)).cuda()
+    x_new = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 72)).cuda()
+    with torch.no_grad():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):           # warm-up on the capture stream (packs weights, sets kernel attributes)
+            for _ in range(2):
+                model(x_static)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = model(x_static)
+        eager_new = model(x_new)
+        x_static.copy_(x_new)
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out["pred_frames"], eager_new["pred_frames"])
+    assert torch.equal(out["bottleneck_rep"], eager_new["bottleneck_rep"])
