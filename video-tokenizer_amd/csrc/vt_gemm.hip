@@ -242,14 +242,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNArgs a) {
 
 }  // namespace
 
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg);
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half);
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s);
 int vt_gemm192_init();
-static int g_gemm_variant = 0;  // 0 auto, 1 force 128x128 tiles, 2 force 192x192 tiles
+static int g_gemm_variant = 0;  // 0 auto, 1 force 128x128 tiles, 2 force 192x192 tiles, 5 force 192x96 tiles (two workgroups per CU)
 
 // test/tuning hook: choose the tile generation used by vt_gemm_nt / vt_gemm_tn_grouped
 extern "C" int vt_set_gemm_variant(int32_t v) {
-    VT_CHECK_ARG(v >= 0 && v <= 4, "vt_set_gemm_variant: 0 auto, 1 = 128x128, 2 = 192x192 (3/4: timing experiments, wrong results)");
+    VT_CHECK_ARG(v >= 0 && v <= 5, "vt_set_gemm_variant: 0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96 (NT only); 3/4: timing experiments, wrong results");
     g_gemm_variant = v;
     return VT_OK;
 }
@@ -281,7 +281,9 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        vt_gemm_nt192_launch(p, (hipStream_t)stream, g_gemm_variant >= 3 ? g_gemm_variant - 2 : 0);
+        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : 0;
+        const int half = g_gemm_variant == 5;
+        vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half);
         VT_CHECK_LAUNCH("vt_gemm_nt(192)");
         return VT_OK;
     }
@@ -308,7 +310,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     TNArgs a;
     a.n = n;
     a.tile_start[0] = 0;
-    bool big = g_gemm_variant != 1 && g_gemm_variant < 3;  // auto: 192x192 tiles when every problem of the group is at least one tile
+    bool big = g_gemm_variant != 1 && (g_gemm_variant < 3 || g_gemm_variant >= 5);  // auto: 192x192 tiles when every problem of the group is at least one tile
     for (int g = 0; g < n; ++g) {
         const vtGemmTN& p = ph[g];
         VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_tn_grouped[%d]: null operand", g);

@@ -34,51 +34,60 @@ __device__ __forceinline__ void raw_barrier() {
 struct NT192Args {
     vtGemmNT p;
     int tiles_m, tiles_n;
-    int dbg;  // timing experiments only (vt_set_gemm_variant 3/4): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads
+    int dbg;      // timing experiments only (vt_set_gemm_variant 3/4): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads
 };
 
-__device__ __forceinline__ void stage_nt192(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0, unsigned lds, int tid, int wave) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int slot = i * 512 + tid;
-        const int row = slot >> 3;
-        const int lc = (slot & 7) ^ ((row >> 1) & 7);
-        int gr = row0 + row;
-        gr = gr < nrows ? gr : nrows - 1;
-        glds16_asm(g + (int64_t)gr * ld + k0 + lc * 8, lds + (i * 512 + wave * 64) * 16);
-    }
-}
+// Geometry of the two NT instantiations.  WN = waves along N (each wave owns 96 x 48 outputs):
+//   WN = 4: 512 threads, 192 x 192 tile, 3-stage ring (144 KiB)  -> one workgroup per CU
+//   WN = 2: 256 threads, 192 x  96 tile, 2-stage ring ( 72 KiB)  -> two workgroups per CU.  Measured (tools/
+//           gemm_half_bench.py): within 0-8 % BEHIND the 192x192 kernel on every training shape.  Co-resident
+//           workgroups start together and stay in phase (the dispatcher puts blocks b and b+256 on one CU,
+//           tools/probes/placement_probe.hip), so their epilogues do not fall into each other's main loops, and a
+//           forced start offset cost more than it recovered.  Kept as a tile option (vt_set_gemm_variant(5)) and as
+//           the record of that experiment; auto dispatch never picks it.
+template <int WN>
+struct NTGeo {
+    static constexpr int THREADS = 128 * WN;
+    static constexpr int TNW = 48 * WN;               // tile extent along N
+    static constexpr int OPA = TM * TK * 2;           // A image bytes
+    static constexpr int OPB = TNW * TK * 2;          // B image bytes
+    static constexpr int STAGE = OPA + OPB;
+    static constexpr int NST = WN == 4 ? 3 : 2;
+    static constexpr int PA = TM * 8 / THREADS;       // 16-B DMA pieces per thread per K-tile, A rows
+    static constexpr int PB = TNW * 8 / THREADS;      // ... B rows
+    static constexpr int P = PA + PB;
+};
 
-// one of the six 16-B-per-lane DMA pieces of a K-tile: pieces 0..2 = A rows, 3..5 = B rows
+// one of the P 16-B-per-lane DMA pieces of a K-tile: pieces 0..PA-1 = A rows, PA..P-1 = B rows
+template <int WN>
 __device__ __forceinline__ void stage_piece_nt192(const bf16_t* __restrict__ A, int64_t lda, int m0, int M, const bf16_t* __restrict__ B,
                                                   int64_t ldb, int n0, int N, int k0, unsigned lds, int piece, int tid, int wave) {
-    const int i = piece < 3 ? piece : piece - 3;
-    const int slot = i * 512 + tid;
+    using G = NTGeo<WN>;
+    const bool isA = piece < G::PA;
+    const int i = isA ? piece : piece - G::PA;
+    const int slot = i * G::THREADS + tid;
     const int row = slot >> 3;
     const int lc = (slot & 7) ^ ((row >> 1) & 7);
-    int gr = (piece < 3 ? m0 : n0) + row;
-    const int lim = piece < 3 ? M : N;
+    int gr = (isA ? m0 : n0) + row;
+    const int lim = isA ? M : N;
     gr = gr < lim ? gr : lim - 1;
-    const bf16_t* g = piece < 3 ? A + (int64_t)gr * lda : B + (int64_t)gr * ldb;
-    glds16_asm(g + k0 + lc * 8, lds + (piece < 3 ? 0 : OP_BYTES) + (i * 512 + wave * 64) * 16);
+    const bf16_t* g = isA ? A + (int64_t)gr * lda : B + (int64_t)gr * ldb;
+    glds16_asm(g + k0 + lc * 8, lds + (isA ? 0 : G::OPA) + (i * G::THREADS + wave * 64) * 16);
 }
 
-__device__ __forceinline__ bf16x8 frag_nt192(const char* lds, int row, int lchunk) {
-    return *(const bf16x8*)(lds + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
+template <int EPI, int WN>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args a) {
+    using G = NTGeo<WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const vtGemmNT& p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int nwg = a.tiles_m * a.tiles_n;
     const int sid = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * TN_;
+    const int m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * G::TNW;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
 
@@ -96,15 +105,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
     // +i*2048 bytes: an instruction immediate.
     const int arow = wm * 96 + fr, brow = wn * 48 + fr;
     const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4), a_off1 = arow * 128 + (((4 + fq) ^ ((arow >> 1) & 7)) << 4);
-    const unsigned b_off0 = OP_BYTES + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
-    const unsigned b_off1 = OP_BYTES + brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4);
+    const unsigned b_off0 = G::OPA + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
+    const unsigned b_off1 = G::OPA + brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4);
 
     // ---- software pipeline across K-tiles -------------------------------------------------------------------------
     // Tile t is multiplied out of a REGISTER set while the 18 fragment reads of tile t+1 are issued between its MFMA
-    // rows into the other set, and the LDS-DMA of tile t+3 is in flight into the LDS buffer tile t just vacated.
+    // rows into the other set, and the LDS-DMA of tile t+NST is in flight into the LDS buffer tile t just vacated.
     // (Without this, all 8 waves burst-read 144 KB of fragments after every barrier before any MFMA can issue: an
     // ablation with the DMA removed still ran at 88 % of the full kernel's time.)  Reads and DMAs are inline asm, so
-    // every wait is explicit: vmcnt counts this thread's 6 DMA pieces per tile, lgkmcnt(0) closes a tile's reads
+    // every wait is explicit: vmcnt counts this thread's P DMA pieces per tile, lgkmcnt(0) closes a tile's reads
     // before the barrier that lets other waves overwrite that LDS buffer.
 #define VT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define VT_ROW(accrow, bb, aa)                                                                   \
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
     accrow[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[2], aa, accrow[2], 0, 0, 0);          \
     __builtin_amdgcn_sched_barrier(0)
     // compute from set C (a0,b0 = k-step 0; a1,b1 = k-step 1) while prefetching the tile at LDS address `nb` into set N
-#define VT_DMA(k) if (dma_tile >= 0) stage_piece_nt192(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, dma_tile * TK, dma_dst, k, tid, wave)
+#define VT_DMA(k) if ((k) < G::P && dma_tile >= 0) stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, dma_tile * TK, dma_dst, k, tid, wave)
 #define VT_STEP(Ca0, Cb0, Ca1, Cb1, Na0, Nb0, Na1, Nb1, nb, pf)                                                      \
     {                                                                                                                \
         const unsigned na0 = (nb) + a_off0, na1 = (nb) + a_off1, nb0 = (nb) + b_off0, nb1 = (nb) + b_off1;           \
@@ -137,10 +146,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
         VT_DMA(5);                                                                                                   \
         if (pf) { VT_DSR(Na1[0], na1, 0); }                                                                          \
         VT_ROW(acc[0], Cb1, Ca1[0]);                                                                                 \
+        VT_DMA(6);                                                                                                   \
         if (pf) { VT_DSR(Na1[1], na1, 2048); }                                                                       \
         VT_ROW(acc[1], Cb1, Ca1[1]);                                                                                 \
+        VT_DMA(7);                                                                                                   \
         if (pf) { VT_DSR(Na1[2], na1, 4096); }                                                                       \
         VT_ROW(acc[2], Cb1, Ca1[2]);                                                                                 \
+        VT_DMA(8);                                                                                                   \
         if (pf) { VT_DSR(Na1[3], na1, 6144); }                                                                       \
         VT_ROW(acc[3], Cb1, Ca1[3]);                                                                                 \
         if (pf) { VT_DSR(Na1[4], na1, 8192); }                                                                       \
@@ -150,25 +162,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
-    auto issue_tile = [&](int tile) {  // LDS-DMA of K-tile `tile` into ring buffer tile % 3
-        const unsigned dst = sbase + (tile % NSTAGE) * STAGE_BYTES;
-        stage_nt192(A, p.lda, m0, p.M, tile * TK, dst, tid, wave);
-        stage_nt192(B, p.ldb, n0, p.N, tile * TK, dst + OP_BYTES, tid, wave);
+    auto issue_tile = [&](int tile) {  // LDS-DMA of K-tile `tile` into ring buffer tile % NST
+        const unsigned dst = sbase + (tile % G::NST) * G::STAGE;
+#pragma unroll
+        for (int k = 0; k < G::P; ++k) stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, tile * TK, dst, k, tid, wave);
     };
     // make tile `nx` visible to every wave (its DMA landed everywhere) and recycle the buffer of tile nx-1, whose
-    // fragments every wave already holds in registers, for tile nx+2
-    // The 6 DMA pieces of tile nx+2 are issued between the first MFMA rows of the following tile body (VT_DMA), so the
-    // matrix pipe restarts right behind the barrier instead of behind ~150 cycles of DMA issue.
+    // fragments every wave already holds in registers, for tile nx-1+NST.  Its P DMA pieces are issued between the
+    // first MFMA rows of the following tile body (VT_DMA), so the matrix pipe restarts right behind the barrier
+    // instead of behind ~150 cycles of DMA issue.  With 3 stages one younger tile stays in flight across the barrier.
     auto sync_for = [&](int nx) {
-        if (nx + 1 < nt) wait_vmcnt6(); else wait_vmcnt0();
+        if (G::NST == 3 && nx + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::P) : "memory");
+        else wait_vmcnt0();
         raw_barrier();
     };
 
     issue_tile(0);
     if (nt > 1) issue_tile(1);
-    if (nt > 2) issue_tile(2);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nt > 1) wait_vmcnt6();
+    if (G::NST > 2 && nt > 2) issue_tile(2);
+    if (G::NST > 2 && nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::P) : "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::P) : "memory");
     else wait_vmcnt0();
     raw_barrier();
     bf16x8 xa0[6], xb0[3], xa1[6], xb1[3], ya0[6], yb0[3], ya1[6], yb1[3];
@@ -190,18 +203,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
         {
             const bool more = t + 1 < nt;
             if (more) sync_for(t + 1);
-            const unsigned nb = sbase + ((more ? t + 1 : t) % NSTAGE) * STAGE_BYTES;
-            const int dma_tile = (t + 3 < nt && a.dbg != 1) ? t + 3 : -1;  // goes into the buffer tile t just vacated
-            const unsigned dma_dst = sbase + (t % NSTAGE) * STAGE_BYTES;
+            const unsigned nb = sbase + ((more ? t + 1 : t) % G::NST) * G::STAGE;
+            const int dma_tile = (t + G::NST < nt && a.dbg != 1) ? t + G::NST : -1;  // goes into the buffer tile t just vacated
+            const unsigned dma_dst = sbase + (t % G::NST) * G::STAGE;
             if (a.dbg != 2) VT_STEP(xa0, xb0, xa1, xb1, ya0, yb0, ya1, yb1, nb, true)
             if (++t == nt) break;
         }
         {   // tile t from set Y, prefetch tile t+1 into set X
             const bool more = t + 1 < nt;
             if (more) sync_for(t + 1);
-            const unsigned nb = sbase + ((more ? t + 1 : t) % NSTAGE) * STAGE_BYTES;
-            const int dma_tile = (t + 3 < nt && a.dbg != 1) ? t + 3 : -1;
-            const unsigned dma_dst = sbase + (t % NSTAGE) * STAGE_BYTES;
+            const unsigned nb = sbase + ((more ? t + 1 : t) % G::NST) * G::STAGE;
+            const int dma_tile = (t + G::NST < nt && a.dbg != 1) ? t + G::NST : -1;
+            const unsigned dma_dst = sbase + (t % G::NST) * G::STAGE;
             if (a.dbg != 2) VT_STEP(ya0, yb0, ya1, yb1, xa0, xb0, xa1, xb1, nb, true)
             if (++t == nt) break;
         }
@@ -211,6 +224,55 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192_kernel(const NT192Args a) {
 #undef VT_STEP
 #undef VT_DMA
 
+    if constexpr (EPI != VT_EPI_F32) {
+        if ((p.N & 3) == 0) {
+            // bf16 outputs leave through LDS: after the swapped MFMA a lane owns 4 consecutive columns of 16 different
+            // rows, so a direct store instruction touches 16 cache lines with 32 B each (the K -> 0 intercept of
+            // tools/gemm_epilogue_cost.py: 2.4 TB/s of stores).  Staged as bf16(acc + bias) in a [192][TNW] image (row
+            // stride +8 B: the 16 rows of a ds_write_b64 group fall on 16 different bank pairs) and read back row-major,
+            // a store instruction writes 512 contiguous bytes.  GELU / gelu' are applied after the read-back, on the
+            // bf16-rounded value (autocast order).
+            constexpr int UPR = G::TNW / 4;             // 8-B units per tile row
+            constexpr int STRIDE = G::TNW * 2 + 8;      // bytes
+            raw_barrier();                              // every wave is done reading the ring
+            f32x4 b4[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int n = n0 + wn * 48 + j * 16 + fq * 4;
+                b4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 v = acc[i][j] + b4[j];
+                    *(bf16x4*)(smem + (wm * 96 + i * 16 + fr) * STRIDE + (wn * 12 + j * 4 + fq) * 8) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                }
+            __syncthreads();
+            constexpr int UNR = EPI == VT_EPI_BF16_DGELU ? 6 : 2;  // DGELU: several aux loads in flight per thread
+#pragma unroll UNR
+            for (int it = 0; it < TM * UPR / G::THREADS; ++it) {
+                const int slot = it * G::THREADS + tid;
+                const int row = slot / UPR, c = slot - row * UPR;
+                const int m = m0 + row, n = n0 + c * 4;
+                if (m >= p.M || n >= p.N) continue;
+                const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
+                bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
+                if constexpr (EPI == VT_EPI_BF16) {
+                    *(bf16x4*)o = h;
+                } else if constexpr (EPI == VT_EPI_BF16_GELU) {
+                    *(bf16x4*)o = h;
+                    *(bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n) =
+                        (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
+                } else {
+                    const bf16x4 uu = *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n);
+                    *(bf16x4*)o = (bf16x4){f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
+                                           f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))};
+                }
+            }
+            return;
+        }
+    }
     const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -364,20 +426,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
 }  // namespace
 
 // Called by vt_gemm_nt / vt_gemm_tn_grouped (vt_gemm.hip) after argument validation.
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg) {
+template <int WN>
+static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg) {
+    using G = NTGeo<WN>;
     NT192Args a;
     a.p = p;
     a.dbg = dbg;
     a.tiles_m = (p.M + TM - 1) / TM;
-    a.tiles_n = (p.N + TN_ - 1) / TN_;
-    const dim3 grid(a.tiles_m * a.tiles_n), block(512);
-    const size_t lds = NSTAGE * STAGE_BYTES;
+    a.tiles_n = (p.N + G::TNW - 1) / G::TNW;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(G::THREADS);
+    const size_t lds = G::NST * G::STAGE;
     switch (p.epi) {
-        case VT_EPI_BF16: hipLaunchKernelGGL(gemm_nt192_kernel<VT_EPI_BF16>, grid, block, lds, s, a); break;
-        case VT_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_nt192_kernel<VT_EPI_BF16_GELU>, grid, block, lds, s, a); break;
-        case VT_EPI_F32: hipLaunchKernelGGL(gemm_nt192_kernel<VT_EPI_F32>, grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL(gemm_nt192_kernel<VT_EPI_BF16_DGELU>, grid, block, lds, s, a); break;
+        case VT_EPI_BF16: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16, WN>), grid, block, lds, s, a); break;
+        case VT_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16_GELU, WN>), grid, block, lds, s, a); break;
+        case VT_EPI_F32: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_F32, WN>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16_DGELU, WN>), grid, block, lds, s, a); break;
     }
+}
+
+// half == 0: 192x192 tiles, one workgroup per CU; half != 0: 192x96 tiles, two per CU
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half) {
+    if (half) launch_nt192<2>(p, s, dbg);
+    else launch_nt192<4>(p, s, dbg);
     return 0;
 }
 
@@ -394,17 +464,25 @@ int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s) {
     return 0;
 }
 
+template <int EPI, int WN>
+static hipError_t allow_lds_nt() {
+    return hipFuncSetAttribute((const void*)gemm_nt192_kernel<EPI, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<WN>::NST * NTGeo<WN>::STAGE);
+}
+
 int vt_gemm192_init() {
-    // 144 KiB of dynamic LDS exceeds the 64 KiB default: opt in once per kernel
+    // more dynamic LDS than the 64 KiB default: opt in once per kernel
     static bool done = false;
     if (done) return 0;
-    const int lds = NSTAGE * STAGE_BYTES;
     hipError_t e = hipSuccess;
-    e = hipFuncSetAttribute((const void*)gemm_nt192_kernel<VT_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192_kernel<VT_EPI_BF16_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192_kernel<VT_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192_kernel<VT_EPI_BF16_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16, 4>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_GELU, 4>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_F32, 4>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_DGELU, 4>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16, 2>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_GELU, 2>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_F32, 2>();
+    if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_DGELU, 2>();
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
     if (e != hipSuccess) {
         vt_set_error("vt_gemm192_init: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return VT_ERR_LAUNCH;
