@@ -156,8 +156,9 @@ def test_gemm_tn_exact_integers(hip, gemm_variant):
 
 
 # ------------------------------------------------------------------------------------- row kernels
-def test_layernorm_fwd_bwd(hip):
-    rows, dim = 200, 768
+@pytest.mark.parametrize("dim", [768, 384, 128, 1024])   # 384 = the discriminator's width (8-B-per-lane variant)
+def test_layernorm_fwd_bwd(hip, dim):
+    rows = 200
     x = torch.from_numpy(_rand((rows, dim), 20)) * 2 + 0.3
     g = torch.from_numpy(gen.uniform((dim,), 21, 0.5, 1.5))
     b = torch.from_numpy(_rand((dim,), 22, 0.1))
@@ -238,46 +239,49 @@ def test_patchify_unpatchify(hip, pt, p, T, S):
 
 
 # -------------------------------------------------------------------------------------- attention
-def _attn_ref(qkv, B, L, H):
-    q, k, v = qkv.reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
-    att = torch.softmax((q @ k.transpose(-2, -1)) * 0.125, dim=-1)
-    return (att @ v).transpose(1, 2).reshape(B * L, H * 64)
+def _attn_ref(qkv, B, L, H, hd=64):
+    q, k, v = qkv.reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)
+    return (att @ v).transpose(1, 2).reshape(B * L, H * hd)
 
 
-@pytest.mark.parametrize("B,L,H", [(1, 64, 1), (2, 192, 3), (1, 100, 2), (1, 333, 1)])
-def test_attention_fwd_bwd(hip, B, L, H):
-    qkv = bf(_rand((B * L, 3 * H * 64), 50 + L))
-    dO = bf(_rand((B * L, H * 64), 51 + L))
+# head_dim 32 + odd L: the GAN discriminator's attention (loss.py:119-204: 12 heads of 32, cls token => L = 1025)
+@pytest.mark.parametrize("B,L,H,hd", [(1, 64, 1, 64), (2, 192, 3, 64), (1, 100, 2, 64), (1, 333, 1, 64),
+                                      (1, 64, 1, 32), (2, 192, 3, 32), (1, 129, 2, 32), (1, 333, 4, 32)])
+def test_attention_fwd_bwd(hip, B, L, H, hd):
+    qkv = bf(_rand((B * L, 3 * H * hd), 50 + L))
+    dO = bf(_rand((B * L, H * hd), 51 + L))
     x = qkv.float().requires_grad_(True)
-    ref = _attn_ref(x, B, L, H)
+    ref = _attn_ref(x, B, L, H, hd)
     ref.backward(dO.float())
-    o, lse2 = hip.attention_fwd(qkv.cuda(), B, L, H)
+    o, lse2 = hip.attention_fwd(qkv.cuda(), B, L, H, hd)
     torch.cuda.synchronize()
     np.testing.assert_allclose(o.float().cpu().numpy(), ref.detach().numpy(), rtol=2e-2, atol=2e-2)
-    q, k, _ = qkv.float().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
-    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * 0.125, dim=-1) / np.log(2.0)
+    q, k, _ = qkv.float().reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1) / np.log(2.0)
     np.testing.assert_allclose(lse2.cpu().numpy(), lse_ref.numpy(), rtol=1e-3, atol=1e-2)
-    dqkv = hip.attention_bwd(qkv.cuda(), o, dO.cuda(), lse2, B, L, H)
+    dqkv = hip.attention_bwd(qkv.cuda(), o, dO.cuda(), lse2, B, L, H, hd)
     torch.cuda.synchronize()
     g = x.grad
     err = (dqkv.float().cpu() - g).abs().max() / g.abs().max()
     assert err < 3e-2, err
 
 
-def test_attention_integer_identity(hip):
+@pytest.mark.parametrize("hd", [64, 32])
+def test_attention_integer_identity(hip, hd):
     """One-hot V columns + peaked scores: checks the transposed-read PV product element by element."""
     B, L, H = 1, 64, 1
-    q = torch.zeros(L, 64)
-    k = torch.zeros(L, 64)
-    v = torch.zeros(L, 64)
+    q = torch.zeros(L, hd)
+    k = torch.zeros(L, hd)
+    v = torch.zeros(L, hd)
     for i in range(L):
-        q[i, i % 64] = 16.0
-        k[i, i % 64] = 16.0           # score(i,i) = 256*0.125 = 32 >> others (0)
-        v[i, (i * 7 + 3) % 64] = float(i % 13 + 1)
-    qkv = torch.stack([q, k, v], dim=1).reshape(L, 3 * 64).to(torch.bfloat16)
-    o, _ = hip.attention_fwd(qkv.cuda(), B, L, H)
+        q[i, i % hd] = 16.0
+        k[i, i % hd] = 16.0           # score(i,i) = 256/sqrt(hd) >> others (0); hd = 32: rows i, i+32 tie and average
+        v[i, (i * 7 + 3) % hd] = float(i % 13 + 1)
+    qkv = torch.stack([q, k, v], dim=1).reshape(L, 3 * hd).to(torch.bfloat16)
+    o, _ = hip.attention_fwd(qkv.cuda(), B, L, H, hd)
     torch.cuda.synchronize()
-    ref = _attn_ref(qkv.float(), B, L, H)
+    ref = _attn_ref(qkv.float(), B, L, H, hd)
     np.testing.assert_allclose(o.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
 
 

@@ -1,4 +1,4 @@
-// Fused multi-head attention (no mask, head_dim 64) for gfx950: forward with online softmax and the
+// Fused multi-head attention (no mask, head_dim 64 or 32) for gfx950: forward with online softmax and the
 // two recompute backward kernels.  Replaces timm Attention's F.scaled_dot_product_attention inside
 // timm Block (constructed at /root/reference/models/transformer.py:52-59) and its autograd.
 //
@@ -18,26 +18,39 @@
 // Because the own row (query in fwd/dQ, key in dK/dV) sits on the lane, softmax statistics are
 // lane-local: no cross-lane reduction except one exchange between the two lane halves.
 //
-// LDS tile image: [64 rows][64 bf16] = 128-B rows of eight 16-B chunks, physical chunk =
-// logical ^ f(row), f(row) = (((row>>1)&1)<<2) | ((row>>2)&3): conflict-free for BOTH the b128 row
-// reads of a 32x32x16 A operand and the transposed b64 reads (derivation in DESIGN.md).  The image is
-// written lane-linearly by the LDS-DMA, so the XOR goes on the per-lane source address.
+// LDS tile image: [64 rows][HD bf16].  head_dim 64: 128-B rows of eight 16-B chunks, physical chunk =
+// logical ^ f(row), f(row) = (((row>>1)&1)<<2) | ((row>>2)&3); head_dim 32 (the GAN discriminator's heads,
+// /root/reference/models/loss.py:119-204 with cfgs/larp_tokenizer.yaml:130-131): 64-B rows of four chunks,
+// f(row) = (row>>2)&3.  Both are conflict-free for BOTH the b128 row reads of a 32x32x16 A operand and the
+// transposed b64 reads (derivation in DESIGN.md).  The image is written lane-linearly by the LDS-DMA, so the
+// XOR goes on the per-lane source address.
 #include "vt_common.h"
 
 namespace {
 
-constexpr int HD = 64;
-constexpr int TILE = 64 * 128;  // bytes per [64][64] bf16 tile
+template <int HD>
+struct AG {
+    static constexpr int ROWB = HD * 2;       // bytes per tile row
+    static constexpr int TILE = 64 * ROWB;    // bytes per [64][HD] bf16 tile
+    static constexpr int KS = HD / 16;        // k-steps of a product that contracts over head_dim
+    static constexpr int DT = HD / 32;        // 32-wide output tiles along head_dim
+    static constexpr int CH = HD / 8;         // 16-B chunks per row
+};
 
-__device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+template <int HD>
+__device__ __forceinline__ int fsw(int row) {
+    return HD == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+}
 
 // LDS-DMA through inline asm (see glds16_asm): callers drain with dma_drain() before the publishing barrier
+template <int HD>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, unsigned lds, int tid, int wave) {
+    constexpr int CH = AG<HD>::CH;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CH / 4; ++i) {
         const int slot = i * 256 + tid;
-        const int row = slot >> 3;
-        const int lc = (slot & 7) ^ fsw(row);
+        const int row = slot / CH;
+        const int lc = (slot % CH) ^ fsw<HD>(row);
         int gr = row0 + row;
         gr = gr < L ? gr : L - 1;
         glds16_asm(src + (int64_t)gr * rs + lc * 8, lds + (i * 256 + wave * 64) * 16);
@@ -45,14 +58,16 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t 
 }
 
 // A operand of a 32x32x16 MFMA from tile rows r0..r0+31, k-step s (16 columns)
+template <int HD>
 __device__ __forceinline__ bf16x8 rowfrag(const char* lds, int r0, int s, int lane) {
     const int row = r0 + (lane & 31);
     const int lc = 2 * s + (lane >> 5);
-    return *(const bf16x8*)(lds + row * 128 + ((lc ^ fsw(row)) << 4));
+    return *(const bf16x8*)(lds + row * AG<HD>::ROWB + ((lc ^ fsw<HD>(row)) << 4));
 }
 
 // A operand [i = column c0 + (lane&31)][k = tile rows], k order matched to an accumulator used as B:
 // element j  <->  tile row rbase + 16*sp + 8*(j>>2) + 4*(lane>>5) + (j&3)
+template <int HD>
 __device__ __forceinline__ bf16x8 trfrag(const char* lds, int rbase, int sp, int c0, int lane) {
     const int g = lane >> 4, lam = lane & 15;
     const int r0 = rbase + 16 * sp + 4 * (g >> 1) + (lam >> 2);
@@ -60,18 +75,19 @@ __device__ __forceinline__ bf16x8 trfrag(const char* lds, int rbase, int sp, int
     const int cb = c0 + 16 * (g & 1);
     const int lc = (cb >> 3) + ((lam & 3) >> 1);
     const int bo = (lam & 1) << 3;
-    const bf16x4 lo = lds_read_tr16(lds + r0 * 128 + ((lc ^ fsw(r0)) << 4) + bo);
-    const bf16x4 hi = lds_read_tr16(lds + r1 * 128 + ((lc ^ fsw(r1)) << 4) + bo);
+    const bf16x4 lo = lds_read_tr16(lds + r0 * AG<HD>::ROWB + ((lc ^ fsw<HD>(r0)) << 4) + bo);
+    const bf16x4 hi = lds_read_tr16(lds + r1 * AG<HD>::ROWB + ((lc ^ fsw<HD>(r1)) << 4) + bo);
     return cat4(lo, hi);
 }
 
 // own 32 rows as B-operand fragments straight from global: f[s] = X[row0 + (lane&31)][16s + 8*(lane>>5) ..+7]
-__device__ __forceinline__ void load_own(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, int lane, bf16x8 (&f)[4]) {
+template <int KS>
+__device__ __forceinline__ void load_own(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, int lane, bf16x8 (&f)[KS]) {
     int r = row0 + (lane & 31);
     r = r < L ? r : L - 1;
     const bf16_t* p = src + (int64_t)r * rs + 8 * (lane >> 5);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) f[s] = *(const bf16x8*)(p + 16 * s);
+    for (int s = 0; s < KS; ++s) f[s] = *(const bf16x8*)(p + 16 * s);
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int sp) {
@@ -83,12 +99,13 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int sp) {
 
 __device__ __forceinline__ int reg_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// store acc^T[d][own_row] tiles (2 x f32x16) as bf16 into dst[own_row][d], 8 B per store
-__device__ __forceinline__ void store_own(const f32x16 (&acc)[2], float mul, bf16_t* __restrict__ dst, int64_t rs, int row, bool ok, int half) {
+// store acc^T[d][own_row] tiles (DT x f32x16) as bf16 into dst[own_row][d], 8 B per store
+template <int DT>
+__device__ __forceinline__ void store_own(const f32x16 (&acc)[DT], float mul, bf16_t* __restrict__ dst, int64_t rs, int row, bool ok, int half) {
     if (!ok) return;
     bf16_t* p = dst + (int64_t)row * rs;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             bf16x4 v;
@@ -100,8 +117,8 @@ __device__ __forceinline__ void store_own(const f32x16 (&acc)[2], float mul, bf1
 
 // one 64-key tile of the forward: S^T = K.Q^T, online softmax (log2 domain; max taken on the raw scores since
 // the scale is positive), O^T += V^T.P^T.  TAIL masks keys >= L (last tile of a ragged sequence only).
-template <bool TAIL>
-__device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& lsum,
+template <int HD, bool TAIL>
+__device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const bf16x8 (&qf)[HD / 16], f32x16 (&oacc)[HD / 32], float& m, float& lsum,
                                          int key0, int L, float c, int lane, int half) {
     f32x16 sacc[2];
 #pragma unroll
@@ -109,8 +126,8 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc[kt], 0, 0, 0);
+        for (int s = 0; s < HD / 16; ++s)
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(kl, kt * 32, s, lane), qf[s], sacc[kt], 0, 0, 0);
     }
     float mx = -__builtin_inff();
 #pragma unroll
@@ -137,21 +154,24 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
     // unconditional: 16 packed multiplies; a "skip when alpha == 1" branch costs more (the compiler then copies the
     // 32 accumulator registers around the branch every tile)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             const bf16x8 pf = pack8(sacc[kt], sp);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(vl, kt * 32, sp, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+            for (int dt = 0; dt < HD / 32; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(vl, kt * 32, sp, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
         }
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+template <int HD>
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
                                                            int L, int H, int nblk, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,19 +189,22 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     const bf16_t* vb = kb + (int64_t)H * HD;
     const int q0 = blk * 128 + wave * 32;
 
-    bf16x8 qf[4];
-    load_own(qb, rs, q0, L, lane, qf);
+    constexpr int TILE = AG<HD>::TILE, KS = AG<HD>::KS, DT = AG<HD>::DT;
+    bf16x8 qf[KS];
+    load_own<KS>(qb, rs, q0, L, lane, qf);
 
-    f32x16 oacc[2];
+    f32x16 oacc[DT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m = -__builtin_inff(), lsum = 0.f;
 
     const int nt = (L + 63) / 64;
     // LDS: [buffer 0: K | V][buffer 1: K | V]
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    stage64(kb, rs, 0, L, sbase, tid, wave);
-    stage64(vb, rs, 0, L, sbase + TILE, tid, wave);
+    stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
+    stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
     dma_drain();
     __syncthreads();
 
@@ -191,28 +214,29 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            stage64(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
-            stage64(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+            stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
+            stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
         const char* kl = smem + cur * 2 * TILE;
-        fwd_tile<false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
+        fwd_tile<HD, false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
         dma_drain();
         __syncthreads();
     }
     if (nfull < nt) {
         const char* kl = smem + (nfull & 1) * 2 * TILE;
-        fwd_tile<true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane, half);
+        fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane, half);
     }
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const int q = q0 + (lane & 31);
     const bool ok = q < L;
-    store_own(oacc, 1.0f / ltot, o + (int64_t)b * L * H * HD + (int64_t)h * HD, (int64_t)H * HD, q, ok, half);
+    store_own<DT>(oacc, 1.0f / ltot, o + (int64_t)b * L * H * HD + (int64_t)h * HD, (int64_t)H * HD, q, ok, half);
     if (ok && half == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);  // v_log_f32 = log2
 }
 
 // ------------------------------------------------------------------------------------------------
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
 // ------------------------------------------------------------------------------------------------
+template <int HD>
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO, float* __restrict__ delta, int64_t BL, int L, int H) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over BL * H
     if (idx >= BL * H) return;
@@ -222,7 +246,7 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __
     const bf16_t* pd = dO + idx * HD;
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < HD / 8; ++c) {
         const bf16x8 a = *(const bf16x8*)(po + c * 8), d = *(const bf16x8*)(pd + c * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(d[j]);
@@ -231,8 +255,8 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __
     delta[(b * H + h) * L + q] = s;
 }
 
-template <bool TAIL>
-__device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], f32x16 (&dq)[2],
+template <int HD, bool TAIL>
+__device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf16x8 (&qf)[HD / 16], const bf16x8 (&dof)[HD / 16], f32x16 (&dq)[HD / 32],
                                         float my_lse, float my_delta, int key0, int L, float c, int lane, int half) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -240,9 +264,9 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(kl, kt * 32, s, lane), qf[s], sacc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(vl, kt * 32, s, lane), dof[s], dp, 0, 0, 0);
+        for (int s = 0; s < HD / 16; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(kl, kt * 32, s, lane), qf[s], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(vl, kt * 32, s, lane), dof[s], dp, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -254,8 +278,8 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
         for (int sp = 0; sp < 2; ++sp) {
             const bf16x8 dsf = pack8(sacc, sp);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(kl, kt * 32, sp, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < HD / 32; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(kl, kt * 32, sp, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
         }
     }
 }
@@ -263,6 +287,7 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
 // ------------------------------------------------------------------------------------------------
 // dQ: own rows = queries; streams K (row reads + transposed reads) and V (row reads)
 // ------------------------------------------------------------------------------------------------
+template <int HD>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               const float* __restrict__ lse2, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e) {
@@ -281,21 +306,24 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const int q = q0 + (lane & 31);
     const int qc = q < L ? q : L - 1;
 
-    bf16x8 qf[4], dof[4];
-    load_own(qb, rs, q0, L, lane, qf);
-    load_own(dO + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, dof);
+    constexpr int TILE = AG<HD>::TILE, KS = AG<HD>::KS, DT = AG<HD>::DT;
+    bf16x8 qf[KS], dof[KS];
+    load_own<KS>(qb, rs, q0, L, lane, qf);
+    load_own<KS>(dO + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, dof);
     const float my_lse = lse2[((int64_t)b * H + h) * L + qc];
     const float my_delta = delta[((int64_t)b * H + h) * L + qc];
 
-    f32x16 dq[2];
+    f32x16 dq[DT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dq[0][r] = dq[1][r] = 0.f;
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
     const int nt = (L + 63) / 64;
     // LDS: [buffer 0: K | V][buffer 1: K | V]
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    stage64(kb, rs, 0, L, sbase, tid, wave);
-    stage64(vb, rs, 0, L, sbase + TILE, tid, wave);
+    stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
+    stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
     dma_drain();
     __syncthreads();
 
@@ -303,25 +331,26 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            stage64(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
-            stage64(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+            stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
+            stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
         const char* kl = smem + cur * 2 * TILE;
-        dq_tile<false>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, t * 64, L, scale_log2e, lane, half);
+        dq_tile<HD, false>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, t * 64, L, scale_log2e, lane, half);
         dma_drain();
         __syncthreads();
     }
     if (nfull < nt) {
         const char* kl = smem + (nfull & 1) * 2 * TILE;
-        dq_tile<true>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, nfull * 64, L, scale_log2e, lane, half);
+        dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, nfull * 64, L, scale_log2e, lane, half);
     }
-    store_own(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
+    store_own<DT>(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
 }
 
 // one 64-query tile of the dK/dV sweep.  LDS buffer: Q tile | dO tile | lse2[64] | delta[64]
-template <bool TAIL>
-__device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2], f32x16 (&dv)[2],
-                                         int q0, int L, float c, int lane, int half) {
+template <int HD, bool TAIL>
+__device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD / 16], const bf16x8 (&vf)[HD / 16], f32x16 (&dk)[HD / 32],
+                                         f32x16 (&dv)[HD / 32], int q0, int L, float c, int lane, int half) {
+    constexpr int TILE = AG<HD>::TILE;
     const char* do_l = qt_l + TILE;
     const float* lse_l = (const float*)(qt_l + 2 * TILE);
     const float* del_l = lse_l + 64;
@@ -331,9 +360,9 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[4]
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(qt_l, qt * 32, s, lane), kf[s], sacc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+        for (int s = 0; s < HD / 16; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(qt_l, qt * 32, s, lane), kf[s], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
         }
         // this lane's 16 query rows are 4 runs of 4 consecutive rows: rows qt*32 + 8g + 4*half + 0..3
 #pragma unroll
@@ -354,9 +383,9 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[4]
             const bf16x8 pf = pack8(sacc, sp);
             const bf16x8 dsf = pack8(dp, sp);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(do_l, qt * 32, sp, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(qt_l, qt * 32, sp, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+            for (int dt = 0; dt < HD / 32; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(do_l, qt * 32, sp, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(qt_l, qt * 32, sp, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
             }
         }
     }
@@ -365,6 +394,7 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[4]
 // ------------------------------------------------------------------------------------------------
 // dK, dV: own rows = keys; streams Q and dO tiles (both row reads and transposed reads) + lse2/delta
 // ------------------------------------------------------------------------------------------------
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e) {
@@ -385,13 +415,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int k0 = blk * 128 + wave * 32;
     const int key = k0 + (lane & 31);
 
-    bf16x8 kf[4], vf[4];
-    load_own(kb, rs, k0, L, lane, kf);
-    load_own(vb, rs, k0, L, lane, vf);
+    constexpr int TILE = AG<HD>::TILE, KS = AG<HD>::KS, DT = AG<HD>::DT;
+    bf16x8 kf[KS], vf[KS];
+    load_own<KS>(kb, rs, k0, L, lane, kf);
+    load_own<KS>(vb, rs, k0, L, lane, vf);
 
-    f32x16 dk[2], dv[2];
+    f32x16 dk[DT], dv[DT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f;
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
 
     // LDS: per buffer  Q tile | dO tile | lse2[64] | delta[64]
     constexpr int BUF = 2 * TILE + 512;
@@ -399,8 +432,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     auto stage = [&](int t, int buf) {
         const unsigned base = sbase + buf * BUF;
-        stage64(qb, rs, t * 64, L, base, tid, wave);
-        stage64(dob, ors, t * 64, L, base + TILE, tid, wave);
+        stage64<HD>(qb, rs, t * 64, L, base, tid, wave);
+        stage64<HD>(dob, ors, t * 64, L, base + TILE, tid, wave);
         if (wave < 2) {  // wave 0: lse2[64], wave 1: delta[64] by 4-byte LDS-DMA (rows past L clamped; masked at use)
             int qq = t * 64 + lane;
             qq = qq < L ? qq : L - 1;
@@ -415,25 +448,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) stage(t + 1, cur ^ 1);
-        dkv_tile<false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
+        dkv_tile<HD, false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
         dma_drain();
         __syncthreads();
     }
-    if (nfull < nt) dkv_tile<true>(smem + (nfull & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
+    if (nfull < nt) dkv_tile<HD, true>(smem + (nfull & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
     bf16_t* dkb = dqkv + (int64_t)b * L * rs + (int64_t)h * HD + (int64_t)H * HD;
-    store_own(dk, scale, dkb, rs, key, key < L, half);
-    store_own(dv, 1.0f, dkb + (int64_t)H * HD, rs, key, key < L, half);
+    store_own<DT>(dk, scale, dkb, rs, key, key < L, half);
+    store_own<DT>(dv, 1.0f, dkb + (int64_t)H * HD, rs, key, key < L, half);
 }
 
 }  // namespace
 
+template <int HD>
+static void launch_fwd(const void* qkv, int B, int L, int H, void* o, float* lse2, hipStream_t s) {
+    const float sl2 = (HD == 64 ? 0.125f : 0.17677669529663688110f) * 1.44269504088896340736f;
+    const int nblk = (L + 127) / 128;
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2);
+}
+
+template <int HD>
+static void launch_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int L, int H, void* dqkv, float* delta_ws, hipStream_t s) {
+    const float scale = HD == 64 ? 0.125f : 0.17677669529663688110f, sl2 = scale * 1.44269504088896340736f;
+    const int64_t BL = (int64_t)B * L;
+    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((BL * H + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o, (const bf16_t*)dO, delta_ws, BL, L, H);
+    const int nblk = (L + 127) / 128;
+    const dim3 grid(nblk * B * H);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, grid, dim3(256), 2 * (2 * AG<HD>::TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
+}
+
 extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream) {
     VT_CHECK_ARG(qkv && o && lse2, "vt_attention_fwd: null pointer");
-    VT_CHECK_ARG(hd == 64, "vt_attention_fwd: head_dim %d unsupported (64 only)", hd);
+    VT_CHECK_ARG(hd == 64 || hd == 32, "vt_attention_fwd: head_dim %d unsupported (64 or 32)", hd);
     VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_fwd: bad shape");
-    const float sl2 = 0.125f * 1.44269504088896340736f;
-    const int nblk = (L + 127) / 128;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk * B * H), dim3(256), 4 * TILE, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2);
+    if (hd == 64) launch_fwd<64>(qkv, B, L, H, o, lse2, (hipStream_t)stream);
+    else launch_fwd<32>(qkv, B, L, H, o, lse2, (hipStream_t)stream);
     VT_CHECK_LAUNCH("vt_attention_fwd");
     return VT_OK;
 }
@@ -441,16 +491,10 @@ extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H
 extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
                                 int32_t hd, void* dqkv, float* delta_ws, vtStream stream) {
     VT_CHECK_ARG(qkv && o && dO && lse2 && dqkv && delta_ws, "vt_attention_bwd: null pointer");
-    VT_CHECK_ARG(hd == 64, "vt_attention_bwd: head_dim %d unsupported (64 only)", hd);
+    VT_CHECK_ARG(hd == 64 || hd == 32, "vt_attention_bwd: head_dim %d unsupported (64 or 32)", hd);
     VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_bwd: bad shape");
-    hipStream_t s = (hipStream_t)stream;
-    const float scale = 0.125f, sl2 = 0.125f * 1.44269504088896340736f;
-    const int64_t BL = (int64_t)B * L;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((BL * H + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o, (const bf16_t*)dO, delta_ws, BL, L, H);
-    const int nblk = (L + 127) / 128;
-    const dim3 grid(nblk * B * H);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * TILE, s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * (2 * TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
+    if (hd == 64) launch_bwd<64>(qkv, o, dO, lse2, B, L, H, dqkv, delta_ws, (hipStream_t)stream);
+    else launch_bwd<32>(qkv, o, dO, lse2, B, L, H, dqkv, delta_ws, (hipStream_t)stream);
     VT_CHECK_LAUNCH("vt_attention_bwd");
     return VT_OK;
 }

@@ -6,36 +6,44 @@
 
 namespace {
 
+// per-lane vector width of the LayerNorm kernels: a row is 64 lanes x VEC floats x V pieces
+template <int VEC> struct LnVec;
+template <> struct LnVec<4> { typedef f32x4 F; typedef bf16x4 H; };
+template <> struct LnVec<2> { typedef __attribute__((ext_vector_type(2))) float F; typedef bf16x2 H; };
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta, y in bf16, stats saved in fp32
 // ------------------------------------------------------------------------------------------------
-template <int V>  // dim = 256 * V
+template <int V, int VEC>  // dim = 64 * VEC * V: 256..1024 with 16-B accesses, 128 / 384 (the discriminator's width) with 8-B
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xmap, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, int64_t rows,
                                                       bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
-    constexpr int DIM = 256 * V;
+    typedef typename LnVec<VEC>::F F;
+    typedef typename LnVec<VEC>::H Hh;
+    constexpr int DIM = 64 * VEC * V;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 g[V], b[V];
+    F g[V], b[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        g[i] = *(const f32x4*)(gamma + (i * 64 + lane) * 4);
-        b[i] = *(const f32x4*)(beta + (i * 64 + lane) * 4);
+        g[i] = *(const F*)(gamma + (i * 64 + lane) * VEC);
+        b[i] = *(const F*)(beta + (i * 64 + lane) * VEC);
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float* xr = x + xmap(row) * DIM;
-        f32x4 v[V];
+        F v[V];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            v[i] = *(const F*)(xr + (i * 64 + lane) * VEC);
+            if constexpr (VEC == 4) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            else s += v[i][0] + v[i][1];
         }
         const float mu = wave_sum(s) * (1.0f / DIM);
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < V; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < VEC; ++r) {
                 const float d = v[i][r] - mu;
                 q += d * d;
             }
@@ -44,10 +52,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         bf16_t* yr = y + row * DIM;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            bf16x4 o;
+            Hh o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf((v[i][r] - mu) * rs * g[i][r] + b[i][r]);
-            *(bf16x4*)(yr + (i * 64 + lane) * 4) = o;
+            for (int r = 0; r < VEC; ++r) o[r] = f2bf((v[i][r] - mu) * rs * g[i][r] + b[i][r]);
+            *(Hh*)(yr + (i * 64 + lane) * VEC) = o;
         }
         if (lane == 0) {
             mean[row] = mu;
@@ -62,31 +70,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Column partials per workgroup: dgamma = sum dy*xh, dbeta = sum dy, dxsum = sum out (the bias
 // gradient of the Linear whose output this residual stream is).  partial layout [grid][3][DIM].
 // ------------------------------------------------------------------------------------------------
-template <int V>
+template <int V, int VEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, RowMap xmap,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres, int64_t rows,
                                                       float* __restrict__ dx, bf16_t* __restrict__ dxb, float* __restrict__ partial) {
-    constexpr int DIM = 256 * V;
+    typedef typename LnVec<VEC>::F F;
+    typedef typename LnVec<VEC>::H Hh;
+    constexpr int DIM = 64 * VEC * V;
     __shared__ float red[4][DIM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 g[V], ag[V], ab[V], as[V];
+    F g[V], ag[V], ab[V], as[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        g[i] = *(const f32x4*)(gamma + (i * 64 + lane) * 4);
-        ag[i] = ab[i] = as[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        g[i] = *(const F*)(gamma + (i * 64 + lane) * VEC);
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) ag[i][r] = ab[i][r] = as[i][r] = 0.f;
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const int64_t pr = xmap(row);
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[V], a[V];
+        F xh[V], a[V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const f32x4 xv = *(const f32x4*)(x + pr * DIM + (i * 64 + lane) * 4);
-            const bf16x4 dv = *(const bf16x4*)(dy + row * DIM + (i * 64 + lane) * 4);
+            const F xv = *(const F*)(x + pr * DIM + (i * 64 + lane) * VEC);
+            const Hh dv = *(const Hh*)(dy + row * DIM + (i * 64 + lane) * VEC);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < VEC; ++r) {
                 const float d = bf2f(dv[r]);
                 xh[i][r] = (xv[r] - mu) * rs;
                 a[i][r] = d * g[i][r];
@@ -100,18 +111,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const float m2 = wave_sum(s2) * (1.0f / DIM);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            f32x4 o;
+            F o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = rs * (a[i][r] - m1 - xh[i][r] * m2);
+            for (int r = 0; r < VEC; ++r) o[r] = rs * (a[i][r] - m1 - xh[i][r] * m2);
             if (dres) {
-                const f32x4 rv = *(const f32x4*)(dres + pr * DIM + (i * 64 + lane) * 4);
+                const F rv = *(const F*)(dres + pr * DIM + (i * 64 + lane) * VEC);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                for (int r = 0; r < VEC; ++r) o[r] += rv[r];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) as[i][r] += o[r];
-            *(f32x4*)(dx + pr * DIM + (i * 64 + lane) * 4) = o;
-            if (dxb) *(bf16x4*)(dxb + pr * DIM + (i * 64 + lane) * 4) = (bf16x4){f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+            for (int r = 0; r < VEC; ++r) as[i][r] += o[r];
+            *(F*)(dx + pr * DIM + (i * 64 + lane) * VEC) = o;
+            if (dxb) {
+                Hh ob;
+#pragma unroll
+                for (int r = 0; r < VEC; ++r) ob[r] = f2bf(o[r]);
+                *(Hh*)(dxb + pr * DIM + (i * 64 + lane) * VEC) = ob;
+            }
         }
     }
     // cross-wave reduction of the three column partials, one at a time through LDS
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int w = 0; w < 3; ++w) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < V; ++i) *(f32x4*)(&red[wave][(i * 64 + lane) * 4]) = (w == 0 ? ag[i] : (w == 1 ? ab[i] : as[i]));
+        for (int i = 0; i < V; ++i) *(F*)(&red[wave][(i * 64 + lane) * VEC]) = (w == 0 ? ag[i] : (w == 1 ? ab[i] : as[i]));
         __syncthreads();
         for (int c = threadIdx.x; c < DIM; c += 256) out[w * DIM + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
@@ -279,15 +295,18 @@ static inline RowMap to_map(vtRowMap m) { return RowMap{m.grp, m.stride, m.off};
 extern "C" int vt_layernorm_fwd(const float* x, vtRowMap xmap, const float* gamma, const float* beta, float eps, int64_t rows,
                                 int32_t dim, void* y_bf16, float* mean, float* rstd, vtStream stream) {
     VT_CHECK_ARG(x && gamma && beta && y_bf16 && mean && rstd, "vt_layernorm_fwd: null pointer");
-    VT_CHECK_ARG(rows > 0 && dim % 256 == 0 && dim >= 256 && dim <= 1024, "vt_layernorm_fwd: dim=%d must be 256,512,768 or 1024", dim);
+    VT_CHECK_ARG(rows > 0 && ((dim % 256 == 0 && dim >= 256 && dim <= 1024) || dim == 128 || dim == 384),
+                 "vt_layernorm_fwd: dim=%d must be 128, 256, 384, 512, 768 or 1024", dim);
     const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
     hipStream_t s = (hipStream_t)stream;
-#define LN_FWD(V) hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3(grid), dim3(256), 0, s, x, to_map(xmap), gamma, beta, eps, rows, (bf16_t*)y_bf16, mean, rstd)
-    switch (dim / 256) {
-        case 1: LN_FWD(1); break;
-        case 2: LN_FWD(2); break;
-        case 3: LN_FWD(3); break;
-        default: LN_FWD(4); break;
+#define LN_FWD(V, VEC) hipLaunchKernelGGL((ln_fwd_kernel<V, VEC>), dim3(grid), dim3(256), 0, s, x, to_map(xmap), gamma, beta, eps, rows, (bf16_t*)y_bf16, mean, rstd)
+    switch (dim) {
+        case 128: LN_FWD(1, 2); break;
+        case 384: LN_FWD(3, 2); break;
+        case 256: LN_FWD(1, 4); break;
+        case 512: LN_FWD(2, 4); break;
+        case 768: LN_FWD(3, 4); break;
+        default: LN_FWD(4, 4); break;
     }
 #undef LN_FWD
     VT_CHECK_LAUNCH("vt_layernorm_fwd");
@@ -301,16 +320,19 @@ extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xm
                                 const float* rstd, const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16,
                                 float* dgamma, float* dbeta, float* dxsum, void* workspace, vtStream stream) {
     VT_CHECK_ARG(dy_bf16 && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "vt_layernorm_bwd: null pointer");
-    VT_CHECK_ARG(rows > 0 && dim % 256 == 0 && dim >= 256 && dim <= 1024, "vt_layernorm_bwd: dim=%d must be 256,512,768 or 1024", dim);
+    VT_CHECK_ARG(rows > 0 && ((dim % 256 == 0 && dim >= 256 && dim <= 1024) || dim == 128 || dim == 384),
+                 "vt_layernorm_bwd: dim=%d must be 128, 256, 384, 512, 768 or 1024", dim);
     const int grid = (int)((rows + 3) / 4 < VT_LN_BWD_GRID ? (rows + 3) / 4 : VT_LN_BWD_GRID);
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)workspace;
-#define LN_BWD(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy_bf16, x, to_map(xmap), gamma, mean, rstd, dres, rows, dx, (bf16_t*)dx_bf16, part)
-    switch (dim / 256) {
-        case 1: LN_BWD(1); break;
-        case 2: LN_BWD(2); break;
-        case 3: LN_BWD(3); break;
-        default: LN_BWD(4); break;
+#define LN_BWD(V, VEC) hipLaunchKernelGGL((ln_bwd_kernel<V, VEC>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy_bf16, x, to_map(xmap), gamma, mean, rstd, dres, rows, dx, (bf16_t*)dx_bf16, part)
+    switch (dim) {
+        case 128: LN_BWD(1, 2); break;
+        case 384: LN_BWD(3, 2); break;
+        case 256: LN_BWD(1, 4); break;
+        case 512: LN_BWD(2, 4); break;
+        case 768: LN_BWD(3, 4); break;
+        default: LN_BWD(4, 4); break;
     }
 #undef LN_BWD
     VT_CHECK_LAUNCH("vt_layernorm_bwd");
