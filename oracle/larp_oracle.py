@@ -326,6 +326,66 @@ def init_state_dict(cfg, seed=1234, zero_head=False):
     return sd
 
 
+# --------------------------------------------------------------------------------------
+# TransformerDiscriminator  (models/loss.py:119-204)   PARITY UNPINNED: loss.py imports `lpips`
+# at module top and is not importable here; the pieces it is made of are pinned separately
+# (PatchEmbed3D + sincos tables by golden vectors, timm Block by the restatement above).
+# --------------------------------------------------------------------------------------
+
+
+def discriminator_forward(p, cfg, x, emu=False):
+    """loss.py:188-201: x_embedder(x) + pos_embed -> cat(cls, .) -> transformer_encoder_fused (nn.Sequential of
+    timm Blocks, transformer.py:8-31) -> cls row -> LayerNorm(1e-6) -> Linear(D, 1).  `p` uses the module's
+    state-dict keys; cfg: dict(n_heads, n_layers)."""
+    b = x.shape[0]
+    tok = patch_embed3d(x, p["x_embedder.proj.weight"], p["x_embedder.proj.bias"], emu) + p["encoder_pos_embed"]
+    h = torch.cat([p["cls_token"].expand(b, -1, -1), tok], dim=1)
+    for i in range(cfg["n_layers"]):
+        h = block(h, p, f"transformer_encoder.blocks.{i}.", cfg["n_heads"], emu)
+    d = h.shape[-1]
+    z = F.layer_norm(h[:, 0], (d,), p["norm_final.weight"], p["norm_final.bias"], 1e-6)
+    return linear(z, p["fc.weight"], p["fc.bias"], emu)
+
+
+def init_discriminator_state_dict(hidden, n_heads, n_layers, input_size, frame_num, pt, ps, seed=4321):
+    """Deterministic weights in TransformerDiscriminator's state-dict layout (loss.py:131-186 for shapes and
+    distributions; values from oracle/inputs.py)."""
+    from . import inputs as gen
+    D = hidden
+    th, tt = input_size // ps, frame_num // pt
+    s = [seed]
+
+    def nxt():
+        s[0] += 1
+        return s[0]
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    sd = {"x_embedder.proj.weight": T(gen.xavier_uniform((D, 3, pt, ps, ps), nxt())),
+          "x_embedder.proj.bias": T(gen.uniform((D,), nxt(), -0.02, 0.02)),
+          "cls_token": T(gen.uniform((1, 1, D), nxt(), -0.1, 0.1)),
+          "encoder_pos_embed": T(sincos_3d(D, th, tt)).float().reshape(1, th * th * tt, D)}
+    for i in range(n_layers):
+        pre = f"transformer_encoder.blocks.{i}."
+        sd[pre + "norm1.weight"] = T(gen.uniform((D,), nxt(), 0.9, 1.1))
+        sd[pre + "norm1.bias"] = T(gen.uniform((D,), nxt(), -0.05, 0.05))
+        sd[pre + "attn.qkv.weight"] = T(gen.xavier_uniform((3 * D, D), nxt()))
+        sd[pre + "attn.proj.weight"] = T(gen.xavier_uniform((D, D), nxt()))
+        sd[pre + "attn.proj.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
+        sd[pre + "norm2.weight"] = T(gen.uniform((D,), nxt(), 0.9, 1.1))
+        sd[pre + "norm2.bias"] = T(gen.uniform((D,), nxt(), -0.05, 0.05))
+        sd[pre + "mlp.fc1.weight"] = T(gen.xavier_uniform((4 * D, D), nxt()))
+        sd[pre + "mlp.fc1.bias"] = T(gen.uniform((4 * D,), nxt(), -0.02, 0.02))
+        sd[pre + "mlp.fc2.weight"] = T(gen.xavier_uniform((D, 4 * D), nxt()))
+        sd[pre + "mlp.fc2.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
+    sd["norm_final.weight"] = T(gen.uniform((D,), nxt(), 0.9, 1.1))
+    sd["norm_final.bias"] = T(gen.uniform((D,), nxt(), -0.05, 0.05))
+    sd["fc.weight"] = T(gen.xavier_uniform((1, D), nxt()))
+    sd["fc.bias"] = T(gen.uniform((1,), nxt(), -0.02, 0.02))
+    return sd
+
+
 # geometry points of SURVEY §8(d)
 CONFIGS = {
     # name: (frame_num, input_size, pt, p, enc_depth, dec_depth, Nq, d)

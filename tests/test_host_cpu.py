@@ -91,8 +91,34 @@ def test_cpu_tensors_are_refused():
                  lambda: m.decode_from_bottleneck(torch.zeros(1, cfg["bottleneck_token_num"], dtype=torch.long))):
         with pytest.raises(vt.hip.HipError):
             call()
-    with pytest.raises(RuntimeError):
-        m.encoder(x, x)  # sub-modules have no standalone (or CPU) path
+    # standalone sub-module forwards run the same kernels: CPU tensors are refused there too (no CPU path anywhere)
+    tok = torch.zeros(1, 4, 768)
+    for call in (lambda: m.encoder(tok, tok), lambda: m.bottleneck(tok), lambda: m.bottleneck.regularizer(torch.zeros(1, 4, 24)),
+                 lambda: m.x_embedder(x), lambda: m.bottleneck.decode(torch.zeros(1, 4, dtype=torch.long))):
+        with pytest.raises(vt.hip.HipError):
+            call()
+    d = vt.TransformerDiscriminator(128, 4, 1, 32, 2, 8, 3, frame_num=4)
+    with pytest.raises(vt.hip.HipError):
+        d(torch.zeros(1, 3, 4, 32, 32))
+
+
+def test_discriminator_and_loss_module_surface():
+    """state-dict keys / shapes of models/loss.py:119-204 and the registry names of SURVEY §8b"""
+    assert {"transformer_encoder_fused", "transformer_encoder_parallel", "bottleneck", "vq", "larp_tokenizer", "lpips_disc_loss"} <= set(vt.models)
+    d = vt.TransformerDiscriminator(384, 12, 8, 128, 4, 8, 3, frame_num=16)   # cfgs/larp_tokenizer.yaml:130-134
+    sd = d.state_dict()
+    assert sd["x_embedder.proj.weight"].shape == (384, 3, 4, 8, 8) and sd["cls_token"].shape == (1, 1, 384)
+    assert sd["encoder_pos_embed"].shape == (1, 1024, 384) and sd["fc.weight"].shape == (1, 384)
+    assert sd["transformer_encoder.blocks.7.mlp.fc2.weight"].shape == (384, 1536) and d.video_token_num == 1024
+    ref = O.sincos_3d(384, 16, 4)
+    assert np.array_equal(sd["encoder_pos_embed"][0].numpy(), ref.astype(np.float32))
+    assert set(sd) == set(O.init_discriminator_state_dict(384, 12, 8, 128, 16, 4, 8))
+    lm = vt.make({"name": "lpips_disc_loss", "args": {"disc_start": 0, "perceptual_weight": 0.0, "disc_loss": "ns_smooth", "lecam_weight": 0.001,
+                                                      "disc_tran_hidden_size": 128, "disc_tran_n_heads": 4, "disc_tran_n_layers": 1,
+                                                      "disc_tran_temporal_patch_size": 2, "disc_tran_patch_size": 8, "input_spatial_size": 32, "frame_num": 4}})
+    assert [m_ for m_ in lm.trainable_modules()] == [lm.discriminator] and "lecam_ema_real" in lm.state_dict()
+    with pytest.raises(NotImplementedError):
+        vt.TransformerDiscriminator(128, 4, 1, 32, 1, 8, 3)
 
 
 def test_vq_index_mode_follows_reference_flags():

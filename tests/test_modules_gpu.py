@@ -1,0 +1,243 @@
+"""Standalone forwards of the registry's sub-modules and the GAN branch of the step (§8f next-1:
+TransformerDiscriminator + lpips_disc_loss), through the C ABI, against the CPU oracle on the same seeded weights.
+Tolerances are the bf16-MFMA-vs-oracle ones of tests/test_model_gpu.py (relative Frobenius error).  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import inputs as gen
+from oracle import larp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _stack_sd(D, depth, seed):
+    s = [seed]
+
+    def nxt():
+        s[0] += 1
+        return s[0]
+
+    sd = {}
+    for i in range(depth):
+        pre = f"blocks.{i}."
+        sd[pre + "norm1.weight"] = _T(gen.uniform((D,), nxt(), 0.9, 1.1))
+        sd[pre + "norm1.bias"] = _T(gen.uniform((D,), nxt(), -0.05, 0.05))
+        sd[pre + "attn.qkv.weight"] = _T(gen.xavier_uniform((3 * D, D), nxt()))
+        sd[pre + "attn.proj.weight"] = _T(gen.xavier_uniform((D, D), nxt()))
+        sd[pre + "attn.proj.bias"] = _T(gen.uniform((D,), nxt(), -0.02, 0.02))
+        sd[pre + "norm2.weight"] = _T(gen.uniform((D,), nxt(), 0.9, 1.1))
+        sd[pre + "norm2.bias"] = _T(gen.uniform((D,), nxt(), -0.05, 0.05))
+        sd[pre + "mlp.fc1.weight"] = _T(gen.xavier_uniform((4 * D, D), nxt()))
+        sd[pre + "mlp.fc1.bias"] = _T(gen.uniform((4 * D,), nxt(), -0.02, 0.02))
+        sd[pre + "mlp.fc2.weight"] = _T(gen.xavier_uniform((D, 4 * D), nxt()))
+        sd[pre + "mlp.fc2.bias"] = _T(gen.uniform((D,), nxt(), -0.02, 0.02))
+    return sd
+
+
+def _check_param_grads(module, pref, tol=6e-2):
+    bad = []
+    for n, prm in module.named_parameters():
+        assert prm.grad is not None, n
+        e = rel(prm.grad.cpu(), pref[n].grad)
+        if e > tol:
+            bad.append((n, e))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("D,H,Lc,Lq", [(128, 2, 20, 13), (256, 4, 64, 64), (128, 4, 7, 26)])   # head_dim 64, 64, 32
+def test_transformer_encoder_parallel_standalone(D, H, Lc, Lq):
+    import video_tokenizer_amd as vt
+    depth, B = 2, 2
+    m = vt.make({"name": "transformer_encoder_parallel", "args": {"dim": D, "depth": depth, "n_head": H, "head_dim": D // H}})
+    sd = _stack_sd(D, depth, 100 + D)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    ctx_ = _T(gen.normal((B, Lc, D), 1)).requires_grad_(True)
+    qry = _T(gen.normal((B, Lq, D), 2)).requires_grad_(True)
+    w = _T(gen.normal((B, Lq, D), 3))
+    cg, qg = ctx_.detach().cuda().requires_grad_(True), qry.detach().cuda().requires_grad_(True)
+    out = m(cg, qg)
+    (out * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.encoder_parallel(ctx_, qry, p, "", depth, H, emu=True)
+    (ref * w).sum().backward()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert rel(out.cpu(), ref.detach()) < 2e-2
+    assert rel(cg.grad.cpu(), ctx_.grad) < 6e-2 and rel(qg.grad.cpu(), qry.grad) < 6e-2
+    _check_param_grads(m, p)
+
+
+def test_transformer_encoder_fused_frozen_weights_still_give_input_grad():
+    """the generator update runs the discriminator with requires_grad_(False) parameters (larp_tokenizer_trainer.py:263-301)"""
+    import video_tokenizer_amd as vt
+    D, H, depth, B, L = 128, 4, 2, 2, 33
+    m = vt.make({"name": "transformer_encoder_fused", "args": {"dim": D, "depth": depth, "n_head": H, "head_dim": 32}})
+    sd = _stack_sd(D, depth, 7)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().requires_grad_(False)
+    x = _T(gen.normal((B, L, D), 4)).requires_grad_(True)
+    xg = x.detach().cuda().requires_grad_(True)
+    out = m(xg)
+    out.square().sum().backward()
+    p = {k: v.clone() for k, v in sd.items()}
+    h = x
+    for i in range(depth):
+        h = O.block(h, p, f"blocks.{i}.", H, emu=True)
+    h.square().sum().backward()
+    assert rel(out.cpu(), h.detach()) < 2e-2 and rel(xg.grad.cpu(), x.grad) < 6e-2
+    assert all(q.grad is None for q in m.parameters())
+
+
+def _bottleneck(d, K, D, n, stochastic=False):
+    import video_tokenizer_amd as vt
+    return vt.make({"name": "bottleneck", "args": {"bottleneck_dim": d, "norm": "none", "regularizer": {"name": "vq", "args": {
+        "codebook_size": K, "commitment_loss_weight": 0.25, "codebook_loss_weight": 1.0, "entropy_loss_weight": 0.0,
+        "entropy_loss_temperature": 0.01, "l2_normalized": True, "stochastic": stochastic, "stochastic_temperature": 0.03}}}},
+        args={"token_nums": n, "input_dim": D, "output_dim": D})
+
+
+@pytest.mark.parametrize("d,K,D,B,n", [(24, 512, 128, 2, 40), (16, 1024, 256, 1, 64)])
+def test_bottleneck_and_vq_standalone(d, K, D, B, n):
+    m = _bottleneck(d, K, D, n)
+    sd = {"in_linear.weight": _T(gen.xavier_uniform((d, D), 31)), "in_linear.bias": _T(gen.uniform((d,), 32, -0.02, 0.02)),
+          "out_linear.weight": _T(gen.xavier_uniform((D, d), 33)), "out_linear.bias": _T(gen.uniform((D,), 34, -0.02, 0.02)),
+          "regularizer.embedding.weight": _T(gen.kaiming_uniform_codebook(K, d, 35))}
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x = _T(gen.normal((B, n, D), 36)).requires_grad_(True)
+    w = _T(gen.normal((B, n, D), 37))
+    xg = x.detach().cuda().requires_grad_(True)
+    out = m(xg)
+    ((out["output"] * w.cuda()).sum() + 0.7 * out["loss_q"] + 0.3 * out["loss_commit"]).backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    idx = out["bottleneck_rep"].cpu()
+    ref = O.bottleneck_forward(x, p, "", "L", emu=True, force_idx=idx)
+    ((ref["output"] * w).sum() + 0.7 * ref["loss_q"] + 0.3 * ref["loss_commit"]).backward()
+    free = O.bottleneck_forward(x.detach(), sd, "", "L", emu=True)
+    assert (free["bottleneck_rep"] == idx).float().mean().item() >= 0.97
+    assert set(out.keys()) == set(ref.keys())
+    assert out["bottleneck_rep"].shape == (B, n) and out["bottleneck_rep"].dtype == torch.int64
+    for k in ("output", "projected_z", "regularized_z", "unregularized_z", "emb"):
+        assert rel(out[k].cpu().float(), ref[k].detach()) < 2e-2, k
+    for k in ("loss_q", "loss_commit", "loss_codebook", "input_norm_first", "input_norm_last"):
+        np.testing.assert_allclose(float(out[k]), float(ref[k]), rtol=2e-2)
+    assert rel(xg.grad.cpu(), x.grad) < 6e-2
+    _check_param_grads(m, p)
+    # decode paths (bottleneck.py:166-168, 327-344): same kernels as the forward, so bit-equal to it
+    with torch.no_grad():
+        zq = m.regularizer.decode(out["bottleneck_rep"])
+        assert zq.shape == (B, n, d) and torch.equal(zq, out["emb"][out["bottleneck_rep"]])
+        assert torch.equal(m.regularizer.get_codebook_entry(out["bottleneck_rep"], shape=(B * n, d)), zq.reshape(B * n, d))
+        xh = m.decode(out["bottleneck_rep"])
+        assert rel(xh.cpu(), ref["output"].detach()) < 2e-2
+
+
+DISC_TINY = dict(hidden=128, n_heads=4, n_layers=2, input_size=32, frame_num=4, pt=2, ps=8)   # head_dim 32, L = 33
+
+
+def _disc(c):
+    import video_tokenizer_amd as vt
+    m = vt.TransformerDiscriminator(c["hidden"], c["n_heads"], c["n_layers"], c["input_size"], c["pt"], c["ps"], 3, frame_num=c["frame_num"])
+    sd = O.init_discriminator_state_dict(c["hidden"], c["n_heads"], c["n_layers"], c["input_size"], c["frame_num"], c["pt"], c["ps"])
+    m.load_state_dict(sd, strict=True)
+    return m.cuda(), sd
+
+
+def test_discriminator_matches_oracle_forward_and_all_gradients():
+    c = DISC_TINY
+    m, sd = _disc(c)
+    B = 3
+    x = _T(gen.video_clips(B, c["frame_num"], c["input_size"], 41)).requires_grad_(True)
+    xg = x.detach().cuda().requires_grad_(True)
+    logits = m(xg)
+    wl = torch.tensor([[1.0], [-2.0], [0.5]])
+    (logits * wl.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(k != "encoder_pos_embed") for k, v in sd.items()}
+    ref = O.discriminator_forward(p, c, x, emu=True)
+    (ref * wl).sum().backward()
+    assert logits.shape == (B, 1)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), rtol=3e-2, atol=3e-2)
+    assert rel(xg.grad.cpu(), x.grad) < 6e-2          # gradient w.r.t. the video: what the generator update consumes
+    _check_param_grads(m, p)
+
+
+def test_lpips_disc_loss_generator_and_discriminator_branches():
+    import video_tokenizer_amd as vt
+    c = DISC_TINY
+    spec = {"name": "lpips_disc_loss", "args": dict(
+        disc_type="transformer", disc_start=0, disc_self_start=-1, pixelloss_weight=1.0, perceptual_weight=0.0, pixel_loss="l1",
+        lecam_weight=0.001, disc_loss="ns", disc_weight=0.3, r1_gp_weight=0.0, d_update_freq=5, spectral_norm=False,
+        disc_tran_hidden_size=c["hidden"], disc_tran_n_heads=c["n_heads"], disc_tran_n_layers=c["n_layers"],
+        disc_tran_temporal_patch_size=c["pt"], disc_tran_patch_size=c["ps"], input_spatial_size=c["input_size"], frame_num=c["frame_num"])}
+    lm = vt.make(spec)
+    sd = O.init_discriminator_state_dict(c["hidden"], c["n_heads"], c["n_layers"], c["input_size"], c["frame_num"], c["pt"], c["ps"])
+    lm.discriminator.load_state_dict(sd, strict=True)
+    lm = lm.cuda()
+    B = 2
+    real = _T(gen.video_clips(B, c["frame_num"], c["input_size"], 51))
+    fake = (_T(gen.video_clips(B, c["frame_num"], c["input_size"], 52)) * 0.8 + 0.1).requires_grad_(True)
+    # ---- generator branch: D frozen, gradient reaches the reconstruction through the discriminator
+    lm.trainable_requires_grad_(False)
+    fg = fake.detach().cuda().requires_grad_(True)
+    loss, info, _ = lm(real.cuda(), fg, global_step=10, for_discriminator=False)
+    loss.backward()
+    logits_ref = O.discriminator_forward(sd, c, fake, emu=True)
+    ref = (real - fake).abs().mean() + 0.3 * (-torch.nn.functional.logsigmoid(logits_ref).mean())
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-2)
+    assert info["g_loss_weight"] == pytest.approx(0.3)
+    assert rel(fg.grad.cpu(), fake.grad) < 6e-2
+    assert all(q.grad is None for q in lm.discriminator.parameters())
+    # ---- discriminator branch: reconstruction detached, D parameters get gradients, LeCam EMA moves
+    lm.trainable_requires_grad_(True)
+    total, info, none = lm(real.cuda(), fg.detach(), global_step=10, for_discriminator=True)
+    total.backward()
+    assert none is None
+    p = {k: v.clone().requires_grad_(k != "encoder_pos_embed") for k, v in sd.items()}
+    lr_, lf_ = O.discriminator_forward(p, c, real, emu=True), O.discriminator_forward(p, c, fake.detach(), emu=True)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    d_ref = bce(lr_, torch.ones_like(lr_)) + bce(lf_, torch.zeros_like(lf_))
+    lecam = torch.relu(lr_.mean() - 0.0) ** 2 + torch.relu(0.0 - lf_.mean()) ** 2
+    tot_ref = d_ref + 0.001 * (0.001 * lecam)
+    tot_ref.backward()
+    np.testing.assert_allclose(total.item(), tot_ref.item(), rtol=2e-2)
+    _check_param_grads(lm.discriminator, p, tol=8e-2)
+    assert float(lm.lecam_ema_real) != 0.0 or float(lm.lecam_ema_fake) != 0.0
+    # options that are not built say so
+    bad = dict(spec["args"], r1_gp_weight=1.0)
+    with pytest.raises(NotImplementedError):
+        vt.make({"name": "lpips_disc_loss", "args": bad})
+    with pytest.raises(NotImplementedError):
+        vt.make({"name": "lpips_disc_loss", "args": dict(spec["args"], perceptual_weight=1.0)})
+
+
+def test_discriminator_at_the_shipped_size():
+    """cfgs/larp_tokenizer.yaml:130-134 at 16x128x128: hidden 384, 12 heads of 32, 8 layers, pt=4, p=8 => L = 1025."""
+    import video_tokenizer_amd as vt
+    m = vt.TransformerDiscriminator(384, 12, 8, 128, 4, 8, 3, frame_num=16).cuda()
+    B = 2
+    x = torch.from_numpy(gen.video_clips(B, 16, 128, 61)).cuda().requires_grad_(True)
+    logits = m(x)
+    logits.sum().backward()
+    torch.cuda.synchronize()
+    assert logits.shape == (B, 1) and torch.isfinite(logits).all()
+    assert x.grad.shape == x.shape and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    for n, q in m.named_parameters():
+        assert q.grad is not None and torch.isfinite(q.grad).all(), n
+    # linearity of the backward in the upstream gradient: size-independent property
+    x2 = x.detach().clone().requires_grad_(True)
+    (3.0 * m(x2)).sum().backward()
+    assert rel(x2.grad, 3.0 * x.grad) < 2e-2

@@ -3,7 +3,9 @@
 Mirrors /root/reference/models/bottleneck.py: `Bottleneck` (:65-188; in_linear -> regulariser ->
 out_linear, norm='none' only) and `SimpleVectorQuantizer` (:203-344; l2-normalised cosine / L2
 codebook search in three index modes).  State-dict keys: `in_linear.*`, `out_linear.*`,
-`regularizer.embedding.weight`.  Arithmetic: vt_vq_forward / vt_vq_backward + the engine's GEMMs.
+`regularizer.embedding.weight`.  Arithmetic: vt_vq_forward / vt_vq_backward + GEMMs -- fused inside the
+engine when called through LARPTokenizer, through functional.{Linear,VectorQuantize} when the modules are
+called on their own (forward / decode / get_codebook_entry keep the reference's signatures and dict keys).
 """
 import torch
 import torch.nn as nn
@@ -56,7 +58,28 @@ class SimpleVectorQuantizer(nn.Module):
         return float(self.stochastic_temperature_inv) if self.stochastic else 1.0
 
     def forward(self, z):
-        raise RuntimeError("vq runs inside the fused HIP engine (LARPTokenizer); no standalone path")
+        """bottleneck.py:262-324; same dict keys.  The search runs in fp32 on the f32 MFMA path (indices bit-exact
+        against the oracle); stochastic sampling is Gumbel-max with a counter RNG seeded from torch.initial_seed()."""
+        from .functional import VectorQuantize
+        assert len(z.shape) == 3, "Input shape must be (batch, n_tokens, e_dim)"
+        self._calls = getattr(self, "_calls", 0) + 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        rz, idx, lq, lc, lcb, zn, emb = VectorQuantize.apply(z.float(), self.embedding.weight, self.index_mode(), self.l2_normalized,
+                                                              self.inv_tau(), float(self.beta), float(self.codebook_loss_weight), seed)
+        if self.same_index_shape:
+            idx = idx.reshape(rz.shape[0], rz.shape[1])
+        zero = torch.zeros((), device=z.device, dtype=torch.float32)
+        return {"unregularized_z": zn, "emb": emb, "regularized_z": rz, "bottleneck_rep": idx, "loss_q": lq, "loss_commit": lc,
+                "loss_codebook": lcb, "loss_entropy": zero, "per_sample_entropy": zero, "codebook_entropy": zero}
+
+    def get_codebook_entry(self, indices, shape=None):
+        """bottleneck.py:327-341"""
+        from .functional import codebook_entries
+        z_q = codebook_entries(indices, self.embedding.weight, self.l2_normalized)
+        return z_q.reshape(shape) if shape is not None else z_q
+
+    def decode(self, indices):
+        return self.get_codebook_entry(indices)
 
 
 @register("bottleneck")
@@ -83,5 +106,25 @@ class Bottleneck(nn.Module):
         regularizer["args"]["token_nums"] = self.token_nums
         self.regularizer = make(regularizer)
 
+    def project_in(self, x):
+        from .functional import Linear
+        assert len(x.shape) == 3, "Input shape must be (batch, n_tokens, e_dim)"
+        return Linear.apply(x, self.in_linear.weight, self.in_linear.bias)
+
+    def project_out(self, z_cat):
+        from .functional import Linear
+        return Linear.apply(z_cat, self.out_linear.weight, self.out_linear.bias)
+
+    def decode(self, bottleneck_rep):
+        return self.project_out(self.regularizer.decode(bottleneck_rep))
+
     def forward(self, x):
-        raise RuntimeError("bottleneck runs inside the fused HIP engine (LARPTokenizer); no standalone path")
+        """bottleneck.py:170-188; the two norm statistics stay 0-dim device tensors (no .item() sync)"""
+        input_norm_first = torch.norm(x[:, 0, :].float(), dim=-1).mean().detach()
+        input_norm_last = torch.norm(x[:, -1, :].float(), dim=-1).mean().detach()
+        z = self.project_in(x)
+        reg = self.regularizer(z)
+        x_hat = self.project_out(reg["regularized_z"])
+        rep = reg.pop("bottleneck_rep")
+        return {"output": x_hat, "bottleneck_rep": rep, "projected_z": z, "input_norm_first": input_norm_first,
+                "input_norm_last": input_norm_last, **reg}

@@ -68,5 +68,9 @@ class PatchEmbed3D(nn.Module):
             assert H % self.patch_size[1] == 0, f"Input height ({H}) should be divisible by patch size ({self.patch_size[1]})."
             assert W % self.patch_size[2] == 0, f"Input width ({W}) should be divisible by patch size ({self.patch_size[2]})."
 
-    def forward(self, x):
-        raise RuntimeError("PatchEmbed3D runs inside the fused HIP engine (LARPTokenizer.forward/encode); it has no standalone CPU path")
+    def forward(self, x, pos_embed=None):
+        """embed.py:85-116 -> [B, N, D] fp32 (values bf16-rounded like the conv under autocast).  `pos_embed` (an
+        extension): an fp32 [N, D] table added in the GEMM epilogue, as every caller adds one right after."""
+        from .functional import PatchEmbed
+        self.check_input(x)
+        return PatchEmbed.apply(x, self.proj.weight, self.proj.bias, pos_embed)

@@ -148,6 +148,13 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def require_gpu(*tensors):
+    """every compute entry point of this package is GPU-only: refuse CPU tensors before anything is allocated"""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipError("libvt_hip operates on GPU tensors only (no CPU path)")
+
+
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -159,6 +166,7 @@ def stream():
 def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
             aux=None, omap=None, round_bf16=False, out_rows=None):
     """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous)."""
+    require_gpu(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     M, K = A.shape
     N = B.shape[0]
@@ -203,10 +211,10 @@ def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
 
 
-def layernorm_fwd(x, gamma, beta, eps, rows=None, xmap=None):
+def layernorm_fwd(x, gamma, beta, eps, rows=None, xmap=None, y=None):
     dim = x.shape[-1]
     rows = rows if rows is not None else x.numel() // dim
-    y = torch.empty(rows, dim, device=x.device, dtype=torch.bfloat16)
+    y = torch.empty(rows, dim, device=x.device, dtype=torch.bfloat16) if y is None else y
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     check(lib().vt_layernorm_fwd(ptr(x), xmap or IDENT, ptr(gamma), ptr(beta), eps, rows, dim, ptr(y), ptr(mean), ptr(rstd), stream()), "vt_layernorm_fwd")
@@ -242,11 +250,11 @@ def batch_sum(src, batch, n, rmap=None):
     return out
 
 
-def cast_rows(src, rows=None, rmap=None, ldd=None):
+def cast_rows(src, rows=None, rmap=None, ldd=None, dst=None):
     dim = src.shape[-1]
     rows = rows if rows is not None else src.numel() // dim
-    ldd = ldd or dim
-    dst = torch.zeros(rows, ldd, device=src.device, dtype=torch.bfloat16)
+    ldd = ldd or (dst.stride(0) if dst is not None else dim)
+    dst = torch.zeros(rows, ldd, device=src.device, dtype=torch.bfloat16) if dst is None else dst
     check(lib().vt_cast_rows(ptr(src), rmap or IDENT, rows, dim, ptr(dst), ldd, stream()), "vt_cast_rows")
     return dst
 
@@ -281,15 +289,15 @@ def unpatchify(rows, B, C, T, S, pt, p):
     return video
 
 
-def attention_fwd(qkv, B, L, H, hd=64):
-    o = torch.empty(B * L, H * hd, device=qkv.device, dtype=torch.bfloat16)
+def attention_fwd(qkv, B, L, H, hd=64, o=None):
+    o = torch.empty(B * L, H * hd, device=qkv.device, dtype=torch.bfloat16) if o is None else o
     lse2 = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
     check(lib().vt_attention_fwd(ptr(qkv), B, L, H, hd, ptr(o), ptr(lse2), stream()), "vt_attention_fwd")
     return o, lse2
 
 
-def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64):
-    dqkv = torch.empty_like(qkv)
+def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None):
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     delta = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
     check(lib().vt_attention_bwd(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
     return dqkv

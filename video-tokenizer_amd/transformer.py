@@ -3,9 +3,12 @@
 Mirrors /root/reference/models/transformer.py: `transformer_encoder_parallel` (:34-70) builds `depth`
 x timm Block(dim, heads, mlp_ratio=4, qkv_bias=False); forward(context, query) = cat -> blocks ->
 last len(query) rows.  The state-dict keys (`blocks.{i}.norm1.weight`, `attn.qkv.weight`,
-`attn.proj.{weight,bias}`, `norm2.*`, `mlp.fc1.*`, `mlp.fc2.*`) are the checkpoint contract; the
-arithmetic runs in the HIP engine (vt_tokenizer_encode/decode), not here.
+`attn.proj.{weight,bias}`, `norm2.*`, `mlp.fc1.*`, `mlp.fc2.*`) are the checkpoint contract.  Inside
+LARPTokenizer the arithmetic runs in the fused HIP engine (vt_tokenizer_encode/decode); called on their own
+(`models.make({'name': 'transformer_encoder_parallel', ...})(context, query)`, or the discriminator's
+`transformer_encoder_fused`, :9-31) the stacks run the same kernels through functional.BlockStack.
 """
+import torch
 import torch.nn as nn
 
 from .registry import register
@@ -50,10 +53,35 @@ class TransformerEncoderParallel(nn.Module):
         assert dim == head_dim * n_head
         if dropout:
             raise NotImplementedError("dropout > 0 is not built")
-        if head_dim != 64:
-            raise NotImplementedError(f"head_dim {head_dim}: the gfx950 attention kernels are built for head_dim 64")
+        if head_dim not in (32, 64):
+            raise NotImplementedError(f"head_dim {head_dim}: the gfx950 attention kernels are built for head_dim 64 and 32")
         self.dim, self.depth, self.n_head = dim, depth, n_head
         self.blocks = nn.ModuleList([Block(dim, n_head) for _ in range(depth)])
 
     def forward(self, context, query):
-        raise RuntimeError("transformer_encoder_parallel runs inside the fused HIP engine (LARPTokenizer); no standalone path")
+        """transformer.py:62-70: cat([context, query]) -> blocks -> last len(query) rows (fp32 in, fp32 out)"""
+        from .functional import block_stack
+        nq = query.size(1)
+        h = block_stack(torch.cat([context.float(), query.float()], dim=1), self.blocks, self.n_head)
+        return h[:, -nq:, :]
+
+
+@register("transformer_encoder_fused")
+class TransformerEncoderFused(nn.Module):
+    """models/transformer.py:8-31: nn.Sequential of `depth` timm Blocks, forward(x) = blocks(x)"""
+
+    def __init__(self, dim, depth, n_head, head_dim, ff_dim=None, dropout=0.0):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        assert ff_dim is None
+        assert dim == head_dim * n_head
+        if dropout:
+            raise NotImplementedError("dropout > 0 is not built")
+        if head_dim not in (32, 64):
+            raise NotImplementedError(f"head_dim {head_dim}: the gfx950 attention kernels are built for head_dim 64 and 32")
+        self.dim, self.depth, self.n_head = dim, depth, n_head
+        self.blocks = nn.Sequential(*[Block(dim, n_head) for _ in range(depth)])
+
+    def forward(self, x):
+        from .functional import block_stack
+        return block_stack(x.float(), self.blocks, self.n_head)
