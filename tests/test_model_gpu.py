@@ -321,3 +321,47 @@ def test_forward_is_hipgraph_capturable():
         torch.cuda.synchronize()
     assert torch.equal(out["pred_frames"], eager_new["pred_frames"])
     assert torch.equal(out["bottleneck_rep"], eager_new["bottleneck_rep"])
+
+
+def test_rfvd_evaluator_loop_with_injected_detector():
+    """eval/rfvd_evaluator.py:85-155 over this build's model: full-length and shorter clips, MSE/PSNR against the
+    oracle's reconstruction, Frechet distance from an injected feature extractor (the I3D file is not shipped)."""
+    from video_tokenizer_amd.evaluator import UCFrFVDEvaluator
+    from video_tokenizer_amd.metrics import FeatureStats, frechet_distance
+    cfg = O.make_cfg("tiny", frame_num=12)   # >= 12 frames: the evaluator only collects I3D statistics then (:133)
+    model, sd = build(cfg, stochastic=True)
+    model.set_vq_eval_deterministic(True)
+    T, S = cfg["frame_num"], cfg["input_size"]
+    clips = [torch.from_numpy(gen.video_clips(3, T, S, 70 + i)) for i in range(4)]
+    proj = torch.from_numpy(gen.normal((3 * S * S, 12), 75)).cuda()
+
+    def detector(v):  # (B, C, T, H, W) in [-1, 1] -> [B, 12]: fixed random projection of the time-mean frame
+        return v.mean(dim=2).reshape(v.shape[0], -1) @ proj
+
+    lp = lambda a, b: (a - b).abs().mean(dim=(1, 2, 3))  # noqa: E731   stand-in perceptual distance per frame
+    ev = UCFrFVDEvaluator(model, loader=[{"gt": c} for c in clips], detector=detector, perceptual_loss=lp, frame_num=T, crop_size=S)
+    assert model.x_embedder.strict_vid_size is False
+    mse, psnr, fvd, lpv = ev.evaluate()
+    # reference values from the oracle on the same clips (following the GPU's indices)
+    mses, fs_fake, fs_real = [], FeatureStats(), FeatureStats()
+    with torch.no_grad():
+        for c in clips:
+            idx = model.encode_eval(c.cuda())["bottleneck_rep"].cpu()
+            ref = O.tokenizer_forward(sd, cfg, c, "D", emu=True, force_idx=idx)["pred_frames"].clamp(0, 1)
+            mses.append(((c - ref) ** 2).mean(dim=(1, 2, 3, 4)))
+            if T >= 12:
+                fs_fake.append(detector((ref.cuda() - 0.5) * 2).cpu())
+                fs_real.append(detector((c.cuda() - 0.5) * 2).cpu())
+    mref = torch.cat(mses)
+    np.testing.assert_allclose(mse, mref.mean().item(), rtol=3e-2)
+    np.testing.assert_allclose(float(psnr), float((-10 * torch.log10(mref)).mean()), rtol=1e-2)
+    assert torch.isfinite(lpv)
+    if T >= 12:
+        np.testing.assert_allclose(fvd, frechet_distance(fs_fake, fs_real), rtol=5e-2, atol=1e-3)
+    else:
+        assert fvd == -1.0
+    # fewer frames than the training length: PE prefix path (larp_tokenizer.py:430-439, 471-482)
+    if T >= 2 * cfg["temporal_patch_size"]:
+        short = [{"gt": c[:, :, : T // 2]} for c in clips[:1]]
+        m2, p2, f2, _ = UCFrFVDEvaluator(model, loader=short, detector=detector, frame_num=T // 2, crop_size=S).evaluate(no_fvd=True)
+        assert np.isfinite(m2) and f2 == -1.0

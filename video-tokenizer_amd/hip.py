@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvt_hip.so")
+LIB_PATH = os.environ.get("VT_HIP_LIB") or os.path.join(_HERE, "libvt_hip.so")   # VT_HIP_LIB: A/B timing of two builds (tools/)
 _lib = None
 
 c_i32, c_i64, c_f32, c_u64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t
