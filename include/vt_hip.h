@@ -73,6 +73,10 @@ typedef struct {
     const void* aux; int64_t ldaux;          /* bf16 [M,N]                                    */
     vtRowMap omap;                           /* VT_EPI_F32 only                               */
     int32_t round_bf16;                      /* VT_EPI_F32 only                               */
+    float* colsum_partial;                   /* VT_EPI_BF16_DGELU only, optional: fp32 [ceil(M/192), N]; row t = column
+                                                sums of the bf16-rounded output over rows [192 t, 192 t + 192) (fixed
+                                                order, no atomics).  vt_sum_slabs over the rows gives the bias gradient
+                                                of the Linear whose pre-activation is `aux`, without re-reading `out` */
 } vtGemmNT;
 
 int vt_gemm_nt(const vtGemmNT* p_host, vtStream stream);

@@ -343,3 +343,23 @@ def test_vq_stochastic_mode_matches_softmax_distribution(hip):
     # a different seed gives a different draw
     o2 = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 2, inv_tau=1.0 / 0.3, seed=99)
     assert (o2["idx"] != o["idx"]).float().mean() > 0.5
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(200, 320, 128, 0), (700, 768, 192, 0), (400, 96, 64, 5)])
+def test_gemm_nt_dgelu_fused_column_sums(hip, M, N, K, variant):
+    """vtGemmNT.colsum_partial: per-192-row column sums of the rounded output, out of the epilogue (fc1 bias gradient)"""
+    hip.check(hip.lib().vt_set_gemm_variant(variant), "vt_set_gemm_variant")
+    try:
+        A, B = bf(_rand((M, K), 91, 0.5)), bf(_rand((N, K), 92, 0.5))
+        u = bf(_rand((M, N), 93))
+        tiles = (M + 191) // 192
+        part = torch.full((tiles, N), float("nan"), device="cuda")
+        out = hip.gemm_nt(A.cuda(), B.cuda(), hip.EPI_BF16_DGELU, aux=u.cuda(), colsum_partial=part)
+        plain = hip.gemm_nt(A.cuda(), B.cuda(), hip.EPI_BF16_DGELU, aux=u.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain)                                   # the output does not depend on the option
+        want = torch.stack([out[t * 192:(t + 1) * 192].float().sum(0) for t in range(tiles)])
+        np.testing.assert_allclose(part.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(part.sum(0).cpu().numpy(), hip.colsum(out).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    finally:
+        hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")

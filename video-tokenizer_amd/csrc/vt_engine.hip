@@ -83,7 +83,7 @@ struct vtTokenizer {
     size_t patches, zb, zproj, vq_E, vq_wnorm, vq_zn, vq_znorm, vq_idx, vq_rz, vq_rzpad, vq_losses, vq_ws, encoded_int;
     size_t hN, meanH, rstdH, yrows;
     // backward scratch
-    size_t dX, dh, dob, delta, ln_ws, cs_ws, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
+    size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
     // is the next block's dx_out set).
@@ -178,6 +178,7 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
     t->delta = a.take((size_t)c.B * c.H * t->L * 4);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
+    t->cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);  // per-M-tile column sums out of the fc2-dgrad epilogue
     t->dY = a.take(Mvp * Kp * 2); t->dhN = a.take(Mvp * D * 2);
     t->dEncb = a.take(Mqp * D * 2); t->d_rz = a.take(Mqp * 64 * 4); t->dz_pad = a.take(Mqp * 64 * 2);
     t->dTok = a.take(Mvp * D * 2);
@@ -405,8 +406,9 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     // fc2 dgrad fused with GELU': du = (dx_out . W2) * gelu'(u)
     vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, du, D4);
     g.aux = WS(void, b.u); g.ldaux = D4;
+    g.colsum_partial = WS(float, t->cs_part);  // fc1 bias gradient = column sums of du, taken in the epilogue
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_colsum(du, 1, D4, id, M, D4, gr.fc1_b, WS(void, t->cs_ws), s));
+    TRY(vt_sum_slabs(WS(float, t->cs_part), (M + 191) / 192, D4, D4, gr.fc1_b, s));
     // fc1 dgrad
     g = nt(du, D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));

@@ -267,6 +267,8 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     VT_CHECK_ARG(!p.rowmod || p.N % 4 == 0, "vt_gemm_nt: rowmod needs N %% 4 == 0");
     if (p.epi == VT_EPI_BF16_GELU) VT_CHECK_ARG(p.out2 && p.ldo2 % 4 == 0, "vt_gemm_nt: GELU epilogue needs out2");
     if (p.epi == VT_EPI_BF16_DGELU) VT_CHECK_ARG(p.aux && p.ldaux % 4 == 0, "vt_gemm_nt: DGELU epilogue needs aux");
+    VT_CHECK_ARG(!p.colsum_partial || (p.epi == VT_EPI_BF16_DGELU && p.N % 4 == 0),
+                 "vt_gemm_nt: colsum_partial needs the DGELU epilogue and N %% 4 == 0 (it always runs on the 192-row tile kernel)");
     if (p.epi == VT_EPI_F32) {
         VT_CHECK_ARG(!p.residual || p.ldr % 4 == 0, "vt_gemm_nt: ldr must be a multiple of 4");
         VT_CHECK_ARG(!p.rowmod || p.rowmod_period > 0, "vt_gemm_nt: rowmod needs a period");
@@ -277,7 +279,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     // auto dispatch (measured on MI355X, tools/gemm_bench.py, profiles/r01_*_gemm_variants_microbench.log): the
     // 192x192 3-stage kernel is ahead on every training-step shape (N = 768: one tile per CU, no tail wave);
     // problems smaller than one tile (bottleneck in_linear N = 24, out_linear K-padded) stay on 128x128 tiles.
-    const bool big = g_gemm_variant >= 2 || (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192);
+    const bool big = g_gemm_variant >= 2 || p.colsum_partial || (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192);
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;

@@ -249,7 +249,43 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     *(bf16x4*)(smem + (wm * 96 + i * 16 + fr) * STRIDE + (wn * 12 + j * 4 + fq) * 8) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 }
             __syncthreads();
-            constexpr int UNR = EPI == VT_EPI_BF16_DGELU ? 6 : 2;  // DGELU: several aux loads in flight per thread
+            if constexpr (EPI == VT_EPI_BF16_DGELU) {
+                // a thread keeps ONE 4-column group and walks the rows (48 lanes cover a 384-B row, the rest of the wave the
+                // next row), so the column sums of the rounded output -- the bias gradient of the Linear whose
+                // pre-activation is `aux` -- fall out of the epilogue instead of a separate pass over M x N
+                constexpr int RL = G::THREADS / UPR;                 // row lanes (10); RL * UPR of the threads are active
+                const int c = tid % UPR, rl = tid / UPR;
+                const int n = n0 + c * 4;
+                f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+                if (rl < RL && n < p.N) {
+#pragma unroll 5
+                    for (int it = 0; it < (TM + RL - 1) / RL; ++it) {
+                        const int row = it * RL + rl;
+                        const int m = m0 + row;
+                        if (row < TM && m < p.M) {
+                            const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
+                            const bf16x4 uu = *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n);
+                            const bf16x4 r = {f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
+                                              f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))};
+                            *(bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = r;
+                            cs += (f32x4){bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+                        }
+                    }
+                }
+                if (p.colsum_partial) {
+                    float* red = (float*)(smem + TM * STRIDE);       // [RL][TNW], behind the staged image
+                    if (rl < RL) *(f32x4*)(red + rl * G::TNW + c * 4) = cs;
+                    __syncthreads();
+                    if (tid < G::TNW && n0 + tid < p.N) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < RL; ++r) sum += red[r * G::TNW + tid];
+                        p.colsum_partial[(int64_t)(m0 / TM) * p.N + n0 + tid] = sum;
+                    }
+                }
+                return;
+            }
+            constexpr int UNR = 2;
 #pragma unroll UNR
             for (int it = 0; it < TM * UPR / G::THREADS; ++it) {
                 const int slot = it * G::THREADS + tid;
@@ -260,14 +296,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
                 if constexpr (EPI == VT_EPI_BF16) {
                     *(bf16x4*)o = h;
-                } else if constexpr (EPI == VT_EPI_BF16_GELU) {
+                } else {
                     *(bf16x4*)o = h;
                     *(bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n) =
                         (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
-                } else {
-                    const bf16x4 uu = *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n);
-                    *(bf16x4*)o = (bf16x4){f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
-                                           f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))};
                 }
             }
             return;

@@ -27,7 +27,7 @@ class GemmNT(ctypes.Structure):
     _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("epi", c_i32), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64), ("bias", c_vp),
                 ("residual", c_vp), ("ldr", c_i64), ("rowmod", c_vp), ("rowmod_period", c_i32), ("aux", c_vp),
-                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32)]
+                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp)]
 
 
 class GemmTN(ctypes.Structure):
@@ -164,7 +164,7 @@ def stream():
 # ---------------------------------------------------------------------------------------------
 
 def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
-            aux=None, omap=None, round_bf16=False, out_rows=None):
+            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None):
     """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous)."""
     require_gpu(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
@@ -187,6 +187,7 @@ def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, r
     p.aux, p.ldaux = (aux.data_ptr(), aux.stride(0)) if aux is not None else (None, 0)
     p.omap = omap if omap is not None else IDENT
     p.round_bf16 = int(round_bf16)
+    p.colsum_partial = colsum_partial.data_ptr() if colsum_partial is not None else None
     check(lib().vt_gemm_nt(ctypes.byref(p), stream()), "vt_gemm_nt")
     return (out, out2) if epi == EPI_BF16_GELU else out
 
