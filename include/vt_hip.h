@@ -180,7 +180,9 @@ int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float
  * oracle/vq_oracle.c (sequential fp32 FMA chain; lowest index wins ties).
  * Backward: gscal = device {dL/dloss_q, dL/dloss_commit, dL/dloss_codebook} (may be NULL);
  * g_rz = dL/dregularized_z fp32 [N,ldg] (may be NULL); outputs dz_in (fp32 [N,d] and/or bf16
- * [N,ldp]) and the dense codebook gradient dW [K,d] (deterministic, no atomics).
+ * [N,ldp]) and the dense codebook gradient dW [K,d] (deterministic, no atomics: one-hot product on the exact
+ * fp32 MFMA, cost independent of how the tokens spread over the codes).  `workspace`: vt_vq_workspace_bytes(N,K,d)
+ * bytes, the forward's scratch may be reused.
  * ------------------------------------------------------------------------------------------ */
 size_t vt_vq_workspace_bytes(int32_t N, int32_t K, int32_t d);
 int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
@@ -190,7 +192,7 @@ int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t
 int vt_vq_backward(const float* g_rz, int64_t ldg, const float* gscal, float beta, float codebook_w, const float* zn,
                    const float* znorm, const float* E, const float* wnorm, const int64_t* idx, int32_t N, int32_t K,
                    int32_t d, int32_t l2_normalized, float* dz_in, void* dz_pad_bf16, int64_t ldp, float* dW,
-                   vtStream stream);
+                   void* workspace, vtStream stream);
 /* get_codebook_entry (bottleneck.py:327-344): E = normalise(codebook) then out[n,:] = E[idx[n],:] */
 int vt_vq_prep_codebook(const float* codebook, int32_t K, int32_t d, int32_t l2_normalized, float* E, float* wnorm,
                         void* workspace, vtStream stream);

@@ -300,56 +300,91 @@ __global__ void vq_bwd_tokens_kernel(const float* __restrict__ g_rz, int64_t ldg
     }
 }
 
-// Dense codebook gradient, deterministic and atomic-free: de[k] = sum_{n: idx[n]==k} s_b*2(q-z)/M in ascending n
-// per lane, then a fixed tree; dW[k] = (de - e (e.de)) / |w_k|  (F.embedding sparse=False through F.normalize).
-// One workgroup owns CPB consecutive codes (one wave per code at a time) and keeps the whole index vector in LDS
-// as int32, so the N x K membership scan never touches HBM: 16 B per lane per LDS read, 4 indices per compare step.
-template <int DMAX>
-__global__ __launch_bounds__(256) void vq_bwd_codebook_kernel(const float* __restrict__ gscal, float beta, float cbw,
-                                                               const float* __restrict__ zn, const float* __restrict__ E,
-                                                               const float* __restrict__ wnorm, const int64_t* __restrict__ idx, int N,
-                                                               int K, int d, int normalize, int codes_per_block, float* __restrict__ dW) {
-    extern __shared__ __attribute__((aligned(16))) int lds_idx[];  // N rounded up to 256, padded with -1
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int Np = (N + 255) & ~255;
-    for (int n = threadIdx.x; n < Np; n += 256) lds_idx[n] = n < N ? (int)idx[n] : -1;
-    __syncthreads();
-    const float s_b = (gscal ? gscal[0] * cbw + gscal[2] : 0.f) * 2.0f / ((float)N * (float)d);
-    const int k_begin = blockIdx.x * codes_per_block;
-    for (int kk = wave; kk < codes_per_block; kk += 4) {
-        const int k = k_begin + kk;
-        if (k >= K) break;
-        const float* e = E + (int64_t)k * d;
-        float acc[DMAX];
+// Dense codebook gradient (F.embedding sparse=False through F.normalize), deterministic, atomic-free and INDEPENDENT OF
+// HOW THE TOKENS SPREAD OVER THE CODES: de[k] = sum_n [idx[n] == k] (e_k - z_n) is a product OneHot^T . (Q - Z) and
+// runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: products with 1.0 / 0.0 are exact, the accumulation is a
+// sequential fp32 chain over ascending n).  A membership scan per code (the first version) was 10 us when the tokens
+// spread evenly and 390 us when they sat on one code -- which is what early training and random weights look like.
+//   grid (ceil(K/128), NS): a wave owns 32 codes x one slab of tokens; 64-token chunks of (q_n - z_n) rows are staged
+//   in LDS once per workgroup; a wave skips every token pair none of whose indices falls in its 32 codes, so the
+//   evenly-spread case costs ~one MFMA per member.  Slab partials [NS][K][d] are summed in ascending slab order by
+//   vq_bwd_codebook_finalize, which also applies the scale and the normalisation Jacobian
+//   dW[k] = (de - e (e.de)) / |w_k|.
+constexpr int CB_CHUNK = 64;
+__global__ __launch_bounds__(256) void vq_bwd_codebook_mfma_kernel(const float* __restrict__ zn, const float* __restrict__ E,
+                                                                    const int64_t* __restrict__ idx, int N, int K, int d, int slab_len,
+                                                                    float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float vals[CB_CHUNK][32];
+    __shared__ int idxs[CB_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const int n_begin = blockIdx.y * slab_len;
+    const int n_end = min(N, n_begin + slab_len);
+    f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < DMAX; ++j) acc[j] = 0.f;
-        for (int n0 = lane * 4; n0 < Np; n0 += 256) {
-            const int4 v = *(const int4*)(lds_idx + n0);
-            const int hit[4] = {v.x == k, v.y == k, v.z == k, v.w == k};
-            if (hit[0] | hit[1] | hit[2] | hit[3]) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (hit[u]) {
-                        const float* z = zn + (int64_t)(n0 + u) * d;
-#pragma unroll
-                        for (int j = 0; j < DMAX; ++j)
-                            if (j < d) acc[j] += e[j] - z[j];
-                    }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int tok = tid >> 2, q8 = (tid & 3) * 8;   // staging role: token of the chunk, 8 of its 32 (padded) dims
+    for (int c0 = n_begin; c0 < n_end; c0 += CB_CHUNK) {
+        {
+            const int n = c0 + tok;
+            const int code = n < n_end ? (int)idx[n] : -1;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (code >= 0 && q8 < d) {
+                const f32x4* e4 = (const f32x4*)(E + (int64_t)code * d + q8);
+                const f32x4* z4 = (const f32x4*)(zn + (int64_t)n * d + q8);
+                v0 = e4[0] - z4[0];
+                v1 = e4[1] - z4[1];
+            }
+            *(f32x4*)&vals[tok][q8] = v0;
+            *(f32x4*)&vals[tok][q8 + 4] = v1;
+            if ((tid & 3) == 0) idxs[tok] = code;
+        }
+        __syncthreads();
+        const unsigned long long mine = __ballot((unsigned)(idxs[lane] - k0) < 32u);   // tokens of this chunk on my 32 codes
+        if (mine) {
+#pragma unroll 4
+            for (int t = 0; t < CB_CHUNK / 2; ++t) {
+                if ((mine >> (2 * t)) & 3ull) {
+                    const float a = (idxs[2 * t + half] == k0 + col) ? 1.0f : 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vals[2 * t + half][col], acc, 0, 0, 0);
+                }
             }
         }
-        float dot = 0.f;
+        __syncthreads();
+    }
+    if (col < d) {
+        float* out = part + ((int64_t)blockIdx.y * K) * d + col;
 #pragma unroll
-        for (int j = 0; j < DMAX; ++j) {
-            acc[j] = wave_sum(acc[j]) * s_b;
-            if (j < d) dot += e[j] * acc[j];
-        }
-        if (lane == 0) {
-            const float inv = 1.0f / wnorm[k];
-#pragma unroll
-            for (int j = 0; j < DMAX; ++j)
-                if (j < d) dW[(int64_t)k * d + j] = normalize ? (acc[j] - e[j] * dot) * inv : acc[j];
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (k < K) out[(int64_t)k * d] = acc[r];
         }
     }
+}
+
+// 32 lanes per code: lane j sums the slab partials of dimension j in ascending slab order
+__global__ __launch_bounds__(256) void vq_bwd_codebook_finalize(const float* __restrict__ part, int nslab, const float* __restrict__ gscal,
+                                                                 float cbw, const float* __restrict__ E, const float* __restrict__ wnorm,
+                                                                 int N, int K, int d, int normalize, float* __restrict__ dW) {
+    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int j = threadIdx.x & 31;
+    const float s_b = (gscal ? gscal[0] * cbw + gscal[2] : 0.f) * 2.0f / ((float)N * (float)d);
+    float de = 0.f, e = 0.f;
+    if (k < K && j < d) {
+        for (int s = 0; s < nslab; ++s) de += part[((int64_t)s * K + k) * d + j];
+        de *= s_b;
+        e = E[(int64_t)k * d + j];
+    }
+    float dot = e * de;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (k < K && j < d) dW[(int64_t)k * d + j] = normalize ? (de - e * dot) / wnorm[k] : de;
+}
+
+static inline int cb_slabs(int N) {
+    int ns = (N + 511) / 512;
+    return ns < 1 ? 1 : (ns > 32 ? 32 : ns);
 }
 
 }  // namespace
@@ -373,7 +408,8 @@ extern "C" size_t vt_vq_workspace_bytes(int32_t N, int32_t K, int32_t d) {
     int S, cps;
     vq_split_plan(N, Kp, &S, &cps);
     size_t f = (size_t)d * Kp + Kp + N + 2 * (size_t)S * N + (N + 255) / 256 + 64;
-    return f * 4;
+    const size_t bwd = (size_t)cb_slabs(N) * K * d;  // slab partials of the codebook gradient (vt_vq_backward)
+    return (f > bwd ? f : bwd) * 4;
 }
 
 extern "C" int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
@@ -444,21 +480,16 @@ extern "C" int vt_vq_prep_codebook(const float* codebook, int32_t K, int32_t d, 
 extern "C" int vt_vq_backward(const float* g_rz, int64_t ldg, const float* gscal, float beta, float codebook_w, const float* zn,
                               const float* znorm, const float* E, const float* wnorm, const int64_t* idx, int32_t N, int32_t K,
                               int32_t d, int32_t l2_normalized, float* dz_in, void* dz_pad_bf16, int64_t ldp, float* dW,
-                              vtStream stream) {
-    VT_CHECK_ARG(zn && znorm && E && wnorm && idx && (dz_in || dz_pad_bf16) && dW, "vt_vq_backward: null pointer");
-    VT_CHECK_ARG(N > 0 && K > 0 && d > 0 && d <= 64, "vt_vq_backward: d=%d out of range", d);
+                              void* workspace, vtStream stream) {
+    VT_CHECK_ARG(zn && znorm && E && wnorm && idx && (dz_in || dz_pad_bf16) && dW && workspace, "vt_vq_backward: null pointer");
+    VT_CHECK_ARG(N > 0 && K > 0 && (d == 8 || d == 16 || d == 24 || d == 32), "vt_vq_backward: d=%d must be 8,16,24 or 32", d);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(vq_bwd_tokens_kernel, dim3((N + 255) / 256), dim3(256), 0, s, g_rz, ldg, gscal, beta, codebook_w, zn, znorm, E, idx, N, d, l2_normalized, dz_in, (bf16_t*)dz_pad_bf16, ldp);
-    VT_CHECK_ARG(N <= 36864, "vt_vq_backward: N=%d tokens exceed the LDS index staging (36864)", N);
-    const int cpb = 16;  // codes per workgroup: K/16 workgroups (512 at K = 8192)
-    const size_t lds = (size_t)((N + 255) & ~255) * 4;
-    if (d <= 32) {
-        if (lds > 65536) (void)hipFuncSetAttribute((const void*)vq_bwd_codebook_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(vq_bwd_codebook_kernel<32>, dim3((K + cpb - 1) / cpb), dim3(256), lds, s, gscal, beta, codebook_w, zn, E, wnorm, idx, N, K, d, l2_normalized, cpb, dW);
-    } else {
-        if (lds > 65536) (void)hipFuncSetAttribute((const void*)vq_bwd_codebook_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(vq_bwd_codebook_kernel<64>, dim3((K + cpb - 1) / cpb), dim3(256), lds, s, gscal, beta, codebook_w, zn, E, wnorm, idx, N, K, d, l2_normalized, cpb, dW);
-    }
+    const int ns = cb_slabs(N);
+    const int slab_len = round_up((N + ns - 1) / ns, CB_CHUNK);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(vq_bwd_codebook_mfma_kernel, dim3((K + 127) / 128, ns), dim3(256), 0, s, zn, E, idx, N, K, d, slab_len, part);
+    hipLaunchKernelGGL(vq_bwd_codebook_finalize, dim3((K + 7) / 8), dim3(256), 0, s, part, ns, gscal, codebook_w, E, wnorm, N, K, d, l2_normalized, dW);
     VT_CHECK_LAUNCH("vt_vq_backward");
     return VT_OK;
 }

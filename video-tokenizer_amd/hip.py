@@ -61,7 +61,7 @@ SIGNATURES = {
     "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vt_vq_backward": (c_i32, [c_vp, c_i64, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
-                               c_vp, c_vp, c_i64, c_vp, c_vp]),
+                               c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vt_vq_prep_codebook": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_vq_gather": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "vt_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp]),
@@ -330,7 +330,8 @@ def vq_backward(g_rz, gscal, saved, beta=0.25, codebook_w=1.0, l2_normalized=Tru
     dz = torch.empty(N, d, device=dev)
     dz_pad = torch.zeros(N, ldp, device=dev, dtype=torch.bfloat16) if ldp else None
     dW = torch.empty(K, d, device=dev)
+    ws = _ws(lib().vt_vq_workspace_bytes(N, K, d), dev)
     check(lib().vt_vq_backward(ptr(g_rz), g_rz.stride(0) if g_rz is not None else 0, ptr(gscal), beta, codebook_w, ptr(zn),
                                ptr(saved["znorm"]), ptr(E), ptr(saved["wnorm"]), ptr(saved["idx"]), N, K, d, int(l2_normalized),
-                               ptr(dz), ptr(dz_pad), ldp, ptr(dW), stream()), "vt_vq_backward")
+                               ptr(dz), ptr(dz_pad), ldp, ptr(dW), ptr(ws), stream()), "vt_vq_backward")
     return dz, dz_pad, dW
