@@ -233,28 +233,6 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     if (ok && half == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);  // v_log_f32 = log2
 }
 
-// ------------------------------------------------------------------------------------------------
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-// ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO, float* __restrict__ delta, int64_t BL, int L, int H) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over BL * H
-    if (idx >= BL * H) return;
-    const int h = idx % H;
-    const int64_t bl = idx / H;
-    const bf16_t* po = o + idx * HD;
-    const bf16_t* pd = dO + idx * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-        const bf16x8 a = *(const bf16x8*)(po + c * 8), d = *(const bf16x8*)(pd + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(d[j]);
-    }
-    const int64_t b = bl / L, q = bl % L;
-    delta[(b * H + h) * L + q] = s;
-}
-
 template <int HD, bool TAIL>
 __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf16x8 (&qf)[HD / 16], const bf16x8 (&dof)[HD / 16], f32x16 (&dq)[HD / 32],
                                         float my_lse, float my_delta, int key0, int L, float c, int lane, int half) {
@@ -285,12 +263,15 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
 }
 
 // ------------------------------------------------------------------------------------------------
-// dQ: own rows = queries; streams K (row reads + transposed reads) and V (row reads)
+// dQ: own rows = queries; streams K (row reads + transposed reads) and V (row reads).  Also produces
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d] for its own rows (both operands are one 16-B load per k-step away) and
+// leaves it in `delta` for the dK/dV kernel, which is launched behind this one.
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
-                                                              const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                              bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                              const bf16_t* __restrict__ dO, const float* __restrict__ lse2,
+                                                              float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, int H, int nblk,
+                                                              float scale, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,7 +292,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     load_own<KS>(qb, rs, q0, L, lane, qf);
     load_own<KS>(dO + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, dof);
     const float my_lse = lse2[((int64_t)b * H + h) * L + qc];
-    const float my_delta = delta[((int64_t)b * H + h) * L + qc];
+    float my_delta = 0.f;
+    {
+        bf16x8 of[KS];
+        load_own<KS>(o + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, of);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) my_delta += bf2f(of[s][j]) * bf2f(dof[s][j]);
+        my_delta += __shfl_xor(my_delta, 32);   // the two lane halves hold the two halves of every 16-wide k-step
+        if (q < L && half == 0) delta[((int64_t)b * H + h) * L + q] = my_delta;
+    }
 
     f32x16 dq[DT];
 #pragma unroll
@@ -470,11 +461,9 @@ static void launch_fwd(const void* qkv, int B, int L, int H, void* o, float* lse
 template <int HD>
 static void launch_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int L, int H, void* dqkv, float* delta_ws, hipStream_t s) {
     const float scale = HD == 64 ? 0.125f : 0.17677669529663688110f, sl2 = scale * 1.44269504088896340736f;
-    const int64_t BL = (int64_t)B * L;
-    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((BL * H + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o, (const bf16_t*)dO, delta_ws, BL, L, H);
     const int nblk = (L + 127) / 128;
     const dim3 grid(nblk * B * H);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, grid, dim3(256), 2 * (2 * AG<HD>::TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
 }
 
