@@ -122,37 +122,33 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     accrow[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[2], aa, accrow[2], 0, 0, 0);          \
     __builtin_amdgcn_sched_barrier(0)
     // compute from set C (a0,b0 = k-step 0; a1,b1 = k-step 1) while prefetching the tile at LDS address `nb` into set N
-#define VT_DMA(k) if ((k) < G::P && dma_tile >= 0) stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, dma_tile * TK, dma_dst, k, tid, wave)
+#define VT_DMA_ALL                                                                                                   \
+    if (dma_tile >= 0) {                                                                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < G::P; ++k_)                                                          \
+            stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, dma_tile * TK, dma_dst, k_, tid, wave);     \
+    }
 #define VT_STEP(Ca0, Cb0, Ca1, Cb1, Na0, Nb0, Na1, Nb1, nb, pf)                                                      \
     {                                                                                                                \
         const unsigned na0 = (nb) + a_off0, na1 = (nb) + a_off1, nb0 = (nb) + b_off0, nb1 = (nb) + b_off1;           \
         if (pf) { VT_DSR(Nb0[0], nb0, 0); VT_DSR(Nb0[1], nb0, 2048); }                                               \
         VT_ROW(acc[0], Cb0, Ca0[0]);                                                                                 \
-        VT_DMA(0);                                                                                                   \
         if (pf) { VT_DSR(Nb0[2], nb0, 4096); VT_DSR(Na0[0], na0, 0); }                                               \
         VT_ROW(acc[1], Cb0, Ca0[1]);                                                                                 \
-        VT_DMA(1);                                                                                                   \
         if (pf) { VT_DSR(Na0[1], na0, 2048); VT_DSR(Na0[2], na0, 4096); }                                            \
         VT_ROW(acc[2], Cb0, Ca0[2]);                                                                                 \
-        VT_DMA(2);                                                                                                   \
         if (pf) { VT_DSR(Na0[3], na0, 6144); VT_DSR(Na0[4], na0, 8192); }                                            \
         VT_ROW(acc[3], Cb0, Ca0[3]);                                                                                 \
-        VT_DMA(3);                                                                                                   \
         if (pf) { VT_DSR(Na0[5], na0, 10240); VT_DSR(Nb1[0], nb1, 0); }                                              \
         VT_ROW(acc[4], Cb0, Ca0[4]);                                                                                 \
-        VT_DMA(4);                                                                                                   \
         if (pf) { VT_DSR(Nb1[1], nb1, 2048); VT_DSR(Nb1[2], nb1, 4096); }                                            \
         VT_ROW(acc[5], Cb0, Ca0[5]);                                                                                 \
-        VT_DMA(5);                                                                                                   \
+        VT_DMA_ALL;                                                                                                  \
         if (pf) { VT_DSR(Na1[0], na1, 0); }                                                                          \
         VT_ROW(acc[0], Cb1, Ca1[0]);                                                                                 \
-        VT_DMA(6);                                                                                                   \
         if (pf) { VT_DSR(Na1[1], na1, 2048); }                                                                       \
         VT_ROW(acc[1], Cb1, Ca1[1]);                                                                                 \
-        VT_DMA(7);                                                                                                   \
         if (pf) { VT_DSR(Na1[2], na1, 4096); }                                                                       \
         VT_ROW(acc[2], Cb1, Ca1[2]);                                                                                 \
-        VT_DMA(8);                                                                                                   \
         if (pf) { VT_DSR(Na1[3], na1, 6144); }                                                                       \
         VT_ROW(acc[3], Cb1, Ca1[3]);                                                                                 \
         if (pf) { VT_DSR(Na1[4], na1, 8192); }                                                                       \
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 #undef VT_DSR
 #undef VT_ROW
 #undef VT_STEP
-#undef VT_DMA
+#undef VT_DMA_ALL
 
     if constexpr (EPI != VT_EPI_F32) {
         if ((p.N & 3) == 0) {
