@@ -287,6 +287,26 @@ int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, con
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A stack of timm Blocks on its own (fp32 [B, L, D] in and out): `transformer_encoder_parallel` / `_fused` called
+ * outside LARPTokenizer (models/transformer.py:8-70; cat / slice of context and query stay with the caller) and the
+ * discriminator's encoder (models/loss.py:150-155: width 384, 12 heads of 32, L = 1025).  head_dim 64 or 32; D in
+ * {128,256,384,512,768,1024}; any L.  The forward re-packs the bf16 operand copies of the weights, saves its
+ * activations in `ws` (vt_stack_workspace_bytes, zeroed once by vt_stack_init_workspace -- padded rows must stay
+ * zero) and the backward of the SAME ws returns dL/dx and, unless need_wgrad == 0 (frozen stack: input gradient
+ * only), every parameter gradient (weight gradients of 4 blocks per grouped launch).  A second forward before
+ * the first one's backward needs its own ws.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int32_t B, L, D, H, depth; } vtStackConfig;
+typedef struct vtTokenizer vtStack;
+int vt_stack_create(const vtStackConfig* cfg, vtStack** out);
+void vt_stack_destroy(vtStack* st);
+size_t vt_stack_workspace_bytes(const vtStack* st);
+int vt_stack_init_workspace(vtStack* st, void* ws, vtStream stream);
+int vt_stack_forward(vtStack* st, const vtBlockTensors* blocks_host, const float* x_in, void* ws, float* x_out, vtStream stream);
+int vt_stack_backward(vtStack* st, const vtBlockTensors* blocks_host, const float* dy, void* ws, const vtBlockTensors* grads_host,
+                      float* dx, int32_t need_wgrad, vtStream stream);
+
 #ifdef __cplusplus
 }
 #endif

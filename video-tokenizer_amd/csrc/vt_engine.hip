@@ -253,7 +253,7 @@ static int block_forward(vtTokenizer* t, const BlockBufs& b, const vtBlockTensor
     TRY(vt_layernorm_fwd(x_in, id, w.norm1_w, w.norm1_b, 1e-5f, M, D, WS(void, b.h1), WS(float, b.mean1), WS(float, b.rstd1), s));
     vtGemmNT g = nt(WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_attention_fwd(WS(void, b.qkv), c.B, t->L, c.H, 64, WS(void, b.o), WS(float, b.lse), s));
+    TRY(vt_attention_fwd(WS(void, b.qkv), c.B, t->L, c.H, c.D / c.H, WS(void, b.o), WS(float, b.lse), s));
     g = nt(WS(void, b.o), D, WS(void, b.proj_wb), D, M, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
     g.bias = w.proj_b; g.residual = x_in; g.ldr = D;
     TRY(vt_gemm_nt(&g, s));
@@ -419,7 +419,7 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     g = nt(dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
     // attention backward
-    TRY(vt_attention_bwd(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, 64, dqkv, WS(float, t->delta), s));
+    TRY(vt_attention_bwd(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, c.D / c.H, dqkv, WS(float, t->delta), s));
     // qkv dgrad
     g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
@@ -523,5 +523,95 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
     }
     if (final_through) *final_through = t->final_through;
     VT_CHECK_LAUNCH("vt_tokenizer_backward");
+    return VT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// A stack of timm Blocks on its own: transformer_encoder_parallel / transformer_encoder_fused called outside the
+// tokenizer (models/transformer.py:8-70) and the discriminator's encoder (models/loss.py:150-155).  Same block
+// machinery and workspace discipline as the tokenizer (the vtStack IS a vtTokenizer with only the block plan filled
+// in); head_dim 64 or 32, any L.  One workspace per forward whose backward is still pending.
+// ------------------------------------------------------------------------------------------------
+extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
+    VT_CHECK_ARG(cfg && out, "vt_stack_create: null pointer");
+    const int B = cfg->B, L = cfg->L, D = cfg->D, H = cfg->H, depth = cfg->depth;
+    VT_CHECK_ARG(B > 0 && L > 0 && depth > 0 && H > 0 && D % H == 0 && (D / H == 64 || D / H == 32),
+                 "vt_stack_create: B=%d L=%d D=%d H=%d depth=%d (head_dim must be 64 or 32)", B, L, D, H, depth);
+    VT_CHECK_ARG(D == 128 || D == 384 || (D % 256 == 0 && D <= 1024), "vt_stack_create: width %d unsupported (128, 256, 384, 512, 768, 1024)", D);
+    vtTokenizer* t = new vtTokenizer();
+    memset(&t->c, 0, sizeof(t->c));
+    t->c.B = B; t->c.D = D; t->c.H = H; t->c.depth_enc = depth; t->c.depth_dec = 0;
+    t->Nv = 0; t->L = L;
+    t->M = B * L; t->Mp = round_up(t->M, 128);
+    t->Mv = t->Mvp = t->Mq = t->Mqp = t->Kp = 0;
+    t->D3 = 3 * D; t->D4 = 4 * D;
+    Arena a;
+    const size_t Mp = t->Mp;
+    plan_blocks(t, a, t->enc, depth);
+    t->x_enc.resize(depth + 1);
+    for (auto& x : t->x_enc) x = a.take(Mp * D * 4);
+    t->dX = a.take(Mp * D * 4);
+    for (auto& g : t->gs) {
+        g.dx_out = a.take(Mp * D * 2); g.dx_mid = a.take(Mp * D * 2);
+        g.du = a.take(Mp * t->D4 * 2); g.dqkv = a.take(Mp * t->D3 * 2);
+    }
+    t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
+    t->delta = a.take((size_t)B * H * L * 4);
+    t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(D));
+    t->cs_ws = a.take(vt_colsum_workspace_bytes(t->D4));
+    t->cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);
+    t->ws_bytes = a.off;
+    *out = t;
+    return VT_OK;
+}
+
+extern "C" void vt_stack_destroy(vtStack* t) { delete t; }
+extern "C" size_t vt_stack_workspace_bytes(const vtStack* t) { return t ? t->ws_bytes : 0; }
+
+extern "C" int vt_stack_init_workspace(vtStack* t, void* ws, vtStream stream) {
+    VT_CHECK_ARG(t && ws, "vt_stack_init_workspace: null pointer");
+    if (hipMemsetAsync(ws, 0, t->ws_bytes, (hipStream_t)stream) != hipSuccess) { vt_set_error("vt_stack_init_workspace: memset failed"); return VT_ERR_LAUNCH; }
+    return VT_OK;
+}
+
+extern "C" int vt_stack_forward(vtStack* t, const vtBlockTensors* blocks, const float* x_in, void* ws, float* x_out, vtStream s) {
+    VT_CHECK_ARG(t && blocks && x_in && ws && x_out, "vt_stack_forward: null pointer");
+    const int depth = t->c.depth_enc;
+    const size_t bytes = (size_t)t->M * t->c.D * 4;
+    hipStream_t hs = (hipStream_t)s;
+    (void)hipMemcpyAsync(WS(void, t->x_enc[0]), x_in, bytes, hipMemcpyDeviceToDevice, hs);
+    TRY(pack_blocks(t, t->enc, blocks, ws, s));
+    for (int i = 0; i < depth; ++i)
+        TRY(block_forward(t, t->enc[i], blocks[i], WS(float, t->x_enc[i]), WS(float, t->x_enc[i + 1]), ws, s));
+    (void)hipMemcpyAsync(x_out, WS(void, t->x_enc[depth]), bytes, hipMemcpyDeviceToDevice, hs);
+    VT_CHECK_LAUNCH("vt_stack_forward");
+    return VT_OK;
+}
+
+extern "C" int vt_stack_backward(vtStack* t, const vtBlockTensors* blocks, const float* dy, void* ws, const vtBlockTensors* grads,
+                                 float* dx, int32_t need_wgrad, vtStream s) {
+    VT_CHECK_ARG(t && blocks && dy && ws && grads && dx, "vt_stack_backward: null pointer");
+    const int depth = t->c.depth_enc, D = t->c.D;
+    const size_t bytes = (size_t)t->M * D * 4;
+    const vtRowMap id = {0, 0, 0};
+    hipStream_t hs = (hipStream_t)s;
+    float* dX = WS(float, t->dX);
+    t->pending.clear();
+    t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
+    (void)hipMemcpyAsync(dX, dy, bytes, hipMemcpyDeviceToDevice, hs);
+    TRY(vt_cast_rows(dX, id, t->M, D, WS(void, t->gs[0].dx_out), D, s));
+    TRY(vt_colsum(dX, 0, D, id, t->M, D, grads[depth - 1].fc2_b, WS(void, t->cs_ws), s));
+    for (int i = depth - 1; i >= 0; --i) {
+        TRY(block_backward(t, t->enc[i], blocks[i], grads[i], WS(float, t->x_enc[i]), i > 0 ? grads[i - 1].fc2_b : nullptr, ws, s));
+        if (!need_wgrad) {  // frozen stack (generator-side pass through the discriminator): input gradient only
+            t->pending.clear();
+            t->pending_blocks = 0;
+        } else if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) {
+            TRY(flush_wgrads(t, 0, s));
+        }
+    }
+    (void)hipMemcpyAsync(dx, dX, bytes, hipMemcpyDeviceToDevice, hs);
+    VT_CHECK_LAUNCH("vt_stack_backward");
     return VT_OK;
 }

@@ -276,10 +276,16 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     } else {
         VT_CHECK_ARG(p.omap.grp == 0, "vt_gemm_nt: output row map only with VT_EPI_F32");
     }
-    // auto dispatch (measured on MI355X, tools/gemm_bench.py, profiles/r01_*_gemm_variants_microbench.log): the
-    // 192x192 3-stage kernel is ahead on every training-step shape (N = 768: one tile per CU, no tail wave);
-    // problems smaller than one tile (bottleneck in_linear N = 24, out_linear K-padded) stay on 128x128 tiles.
-    const bool big = g_gemm_variant >= 2 || p.colsum_partial || (g_gemm_variant == 0 && p.N >= 192 && p.M >= 192);
+    // auto dispatch (measured on MI355X: tools/gemm_bench.py, tools/gemm_disc_shapes.py): the 192x192 3-stage kernel is
+    // ahead whenever its tiles fill whole rounds of the 256 CUs (every tokenizer shape: 256 / 768 / 1024 tiles).  Shapes
+    // that leave its last round mostly empty (the discriminator's M = 8 x 1025, N = 384 / 1152: 86 or 258 tiles) finish
+    // sooner on 128x128 tiles, two workgroups per CU; a round of those costs ~0.95 of a 192-round.
+    bool big = g_gemm_variant >= 2 || p.colsum_partial;
+    if (g_gemm_variant == 0 && !big && p.N >= 192 && p.M >= 192) {
+        const long t192 = (long)((p.M + 191) / 192) * ((p.N + 191) / 192), t128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+        const double c192 = (double)((t192 + 255) / 256), c128 = 0.95 * (double)((t128 + 511) / 512);
+        big = c192 <= c128;
+    }
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;

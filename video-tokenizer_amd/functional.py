@@ -11,6 +11,8 @@ Mixed-precision contract = the engine's: fp32 residual stream an
 bf16 MFMA operands with fp32 accumulation, Linear outputs rounded to bf16 where autocast would.
 No CPU path: CPU tensors are refused by hip.ptr().
 """
+import ctypes
+
 import torch
 
 from . import hip
@@ -38,10 +40,42 @@ def block_params(blocks):
     return out
 
 
+_STACKS = {}       # (B, L, D, H, depth) -> (handle, workspace bytes)
+_WS_POOL = {}      # same key -> zero-initialised workspaces whose backward is done (their padded rows are still zero)
+
+
+def _stack(key):
+    h = _STACKS.get(key)
+    if h is None:
+        cfg = hip.StackConfig(*key)
+        out = ctypes.c_void_p()
+        hip.check(hip.lib().vt_stack_create(ctypes.byref(cfg), ctypes.byref(out)), "vt_stack_create")
+        h = (out, int(hip.lib().vt_stack_workspace_bytes(out)))
+        _STACKS[key] = h
+    return h
+
+
+def _take_ws(key, nbytes, dev):
+    pool = _WS_POOL.setdefault((key, str(dev)), [])
+    if pool:
+        return pool.pop()
+    return torch.zeros(nbytes, dtype=torch.uint8, device=dev)   # = vt_stack_init_workspace
+
+
+def _block_array(tensors, depth):
+    arr = (hip.BlockTensors * depth)()
+    for i in range(depth):
+        for j, name in enumerate(hip.BLOCK_FIELDS):
+            setattr(arr[i], name, tensors[i * PARAMS_PER_BLOCK + j].data_ptr())
+    return arr
+
+
 class BlockStack(torch.autograd.Function):
     """depth x timm Block(dim, heads, mlp_ratio=4, qkv_bias=False) on x fp32 [B, L, D]; head_dim 64 or 32, any L.
-    Forward = 8 launches per block, backward = 13 + one grouped weight-gradient launch, the same sequence as
-    vt_engine.hip::block_forward/block_backward (reference: timm Block as built at models/transformer.py:18-25, 52-59)."""
+    One vt_stack_forward / vt_stack_backward call each: the C++ engine enqueues the tokenizer's own block sequence
+    (8 launches per block forward, 13 backward + one grouped weight-gradient launch per 4 blocks; reference: timm Block
+    as built at models/transformer.py:18-25, 52-59).  Frozen parameters (requires_grad False everywhere: the
+    generator-side pass through the discriminator) skip the weight-gradient GEMMs."""
 
     @staticmethod
     def forward(ctx, x, n_head, *params):
@@ -50,77 +84,35 @@ class BlockStack(torch.autograd.Function):
         B, L, D = x.shape
         depth = len(params) // PARAMS_PER_BLOCK
         assert depth * PARAMS_PER_BLOCK == len(params) and D % n_head == 0
-        hd = D // n_head
-        M, Mp, dev = B * L, _pad64(B * L), x.device
-        cur = x.contiguous().reshape(M, D)
-        saved = []
-        for i in range(depth):
-            g1, b1, wqkv, wproj, bproj, g2, b2, wfc1, bfc1, wfc2, bfc2 = params[i * PARAMS_PER_BLOCK:(i + 1) * PARAMS_PER_BLOCK]
-            qkv_b, qkv_t = hip.pack_weight(wqkv)
-            proj_b, proj_t = hip.pack_weight(wproj)
-            fc1_b, fc1_t = hip.pack_weight(wfc1)
-            fc2_b, fc2_t = hip.pack_weight(wfc2)
-            # rows >= M of every buffer a weight-gradient GEMM contracts over stay zero
-            h1 = _zeros(Mp, D, dev)
-            _, mean1, rstd1 = hip.layernorm_fwd(cur, g1, b1, 1e-5, y=h1)
-            qkv = hip.gemm_nt(h1[:M], qkv_b, hip.EPI_BF16)
-            o = _zeros(Mp, D, dev)
-            _, lse = hip.attention_fwd(qkv, B, L, n_head, hd, o=o)
-            x_mid = hip.gemm_nt(o[:M], proj_b, hip.EPI_F32, bias=bproj, residual=cur)
-            h2 = _zeros(Mp, D, dev)
-            _, mean2, rstd2 = hip.layernorm_fwd(x_mid, g2, b2, 1e-5, y=h2)
-            u = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16)
-            g = _zeros(Mp, 4 * D, dev)
-            hip.gemm_nt(h2[:M], fc1_b, hip.EPI_BF16_GELU, bias=bfc1, out=u, out2=g[:M])
-            x_out = hip.gemm_nt(g[:M], fc2_b, hip.EPI_F32, bias=bfc2, residual=x_mid)
-            saved.append(dict(x_in=cur, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, lse=lse, o=o, x_mid=x_mid, h2=h2, mean2=mean2,
-                              rstd2=rstd2, u=u, g=g, qkv_t=qkv_t, proj_t=proj_t, fc1_t=fc1_t, fc2_t=fc2_t))
-            cur = x_out
-        ctx.saved, ctx.geom, ctx.params = saved, (B, L, D, n_head, hd), params
-        return cur.reshape(B, L, D)
+        key = (B, L, D, n_head, depth)
+        handle, nbytes = _stack(key)
+        params = tuple(p_.detach().float().contiguous() for p_ in params)
+        ws = _take_ws(key, nbytes, x.device)
+        xin = x.contiguous()
+        out = torch.empty_like(xin)
+        hip.check(hip.lib().vt_stack_forward(handle, _block_array(params, depth), hip.ptr(xin), hip.ptr(ws), hip.ptr(out), hip.stream()), "vt_stack_forward")
+        if any(ctx.needs_input_grad):     # a backward may follow: the activations stay in ws until then
+            ctx.key, ctx.ws, ctx.params, ctx.done = key, ws, params, False
+        else:                             # inference: the workspace is free again behind this forward (stream order)
+            _WS_POOL[(key, str(x.device))].append(ws)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        B, L, D, H, hd = ctx.geom
-        M, Mp, dev = B * L, _pad64(B * L), dy.device
-        depth = len(ctx.saved)
+        if ctx.done:
+            raise RuntimeError("BlockStack: second backward through the same forward (its workspace was recycled)")
+        B, L, D, H, depth = ctx.key
+        handle, _ = _stack(ctx.key)
         need = ctx.needs_input_grad[2:]
-        grads = [None] * len(ctx.params)
-        dX = dy.contiguous().reshape(M, D).clone()
-        dXa = _zeros(Mp, D, dev)
-        hip.cast_rows(dX, dst=dXa)
-        if need[(depth - 1) * PARAMS_PER_BLOCK + 10]:
-            grads[(depth - 1) * PARAMS_PER_BLOCK + 10] = hip.colsum(dX)
-        for i in range(depth - 1, -1, -1):
-            s = ctx.saved[i]
-            g1, _, wqkv, wproj, _, g2, _, wfc1, _, wfc2, _ = ctx.params[i * PARAMS_PER_BLOCK:(i + 1) * PARAMS_PER_BLOCK]
-            k = i * PARAMS_PER_BLOCK
-            du = _zeros(Mp, 4 * D, dev)
-            hip.gemm_nt(dXa[:M], s["fc2_t"], hip.EPI_BF16_DGELU, aux=s["u"], out=du[:M])
-            if need[k + 8]:
-                grads[k + 8] = hip.colsum(du, rows=M)
-            dh = hip.gemm_nt(du[:M], s["fc1_t"], hip.EPI_BF16)
-            dXm = _zeros(Mp, D, dev)
-            _, _, dg2, db2, dpb = hip.layernorm_bwd(dh, s["x_mid"], g2, s["mean2"], s["rstd2"], dres=dX, dx=dX, dxb=dXm)
-            grads[k + 5], grads[k + 6], grads[k + 4] = dg2, db2, dpb
-            dob = hip.gemm_nt(dXm[:M], s["proj_t"], hip.EPI_BF16)
-            dqkv = _zeros(Mp, 3 * D, dev)
-            hip.attention_bwd(s["qkv"], s["o"], dob, s["lse"], B, L, H, hd, dqkv=dqkv)
-            dh = hip.gemm_nt(dqkv[:M], s["qkv_t"], hip.EPI_BF16)
-            wg = []
-            for idx, A, Bm, w in ((k + 9, dXa, s["g"], wfc2), (k + 7, du, s["h2"], wfc1), (k + 3, dXm, s["o"], wproj), (k + 2, dqkv, s["h1"], wqkv)):
-                if need[idx]:
-                    grads[idx] = torch.empty_like(w, dtype=torch.float32)
-                    wg.append(dict(A=A, B=Bm, out=grads[idx]))
-            if wg:
-                hip.gemm_tn_grouped(wg)
-            dXa = _zeros(Mp, D, dev)
-            _, _, dg1, db1, dxs = hip.layernorm_bwd(dh, s["x_in"], g1, s["mean1"], s["rstd1"], dres=dX, dx=dX, dxb=dXa)
-            grads[k + 0], grads[k + 1] = dg1, db1
-            if i > 0:
-                grads[k - PARAMS_PER_BLOCK + 10] = dxs  # fc2 bias of the block below = column sum of dL/dx_in
-        grads = [g if n else None for g, n in zip(grads, need)]
-        return (dX.reshape(B, L, D), None, *grads)
+        grads = [torch.empty_like(p_) for p_ in ctx.params]     # LayerNorm / bias gradients are always produced
+        dx = torch.empty(B, L, D, device=dy.device, dtype=torch.float32)
+        dyc = dy.contiguous().float()
+        hip.check(hip.lib().vt_stack_backward(handle, _block_array(ctx.params, depth), hip.ptr(dyc), hip.ptr(ctx.ws), _block_array(grads, depth),
+                                              hip.ptr(dx), int(any(need)), hip.stream()), "vt_stack_backward")
+        ctx.done = True
+        _WS_POOL[(ctx.key, str(dy.device))].append(ctx.ws)
+        ctx.ws = None
+        return (dx, None, *[g if n else None for g, n in zip(grads, need)])
 
 
 def block_stack(x, blocks, n_head):

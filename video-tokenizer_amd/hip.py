@@ -80,6 +80,10 @@ class BlockTensors(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in BLOCK_FIELDS]
 
 
+class StackConfig(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("B", "L", "D", "H", "depth")]
+
+
 TENSOR_FIELDS = ("pe_w", "pe_b", "enc_patch_pe", "enc_query", "dec_latent_pe", "dec_patch_query", "dec_token_type", "in_w", "in_b",
                  "out_w", "out_b", "codebook", "head_norm_w", "head_norm_b", "head_w", "head_b")
 
@@ -97,6 +101,12 @@ class TokenizerOutputs(ctypes.Structure):
 
 _TT = ctypes.POINTER(TokenizerTensors)
 ENGINE_SIGNATURES = {
+    "vt_stack_create": (c_i32, [ctypes.POINTER(StackConfig), ctypes.POINTER(c_vp)]),
+    "vt_stack_destroy": (None, [c_vp]),
+    "vt_stack_workspace_bytes": (c_sz, [c_vp]),
+    "vt_stack_init_workspace": (c_i32, [c_vp, c_vp, c_vp]),
+    "vt_stack_forward": (c_i32, [c_vp, ctypes.POINTER(BlockTensors), c_vp, c_vp, c_vp, c_vp]),
+    "vt_stack_backward": (c_i32, [c_vp, ctypes.POINTER(BlockTensors), c_vp, c_vp, ctypes.POINTER(BlockTensors), c_vp, c_i32, c_vp]),
     "vt_tokenizer_create": (c_i32, [ctypes.POINTER(TokenizerConfig), ctypes.POINTER(c_vp)]),
     "vt_tokenizer_destroy": (None, [c_vp]),
     "vt_tokenizer_workspace_bytes": (c_sz, [c_vp]),

@@ -251,8 +251,11 @@ class VQLPIPSWithDiscriminator(nn.Module):
             return loss, info, 0
         disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_self_start)
         if disc_factor > 0.0:
-            logits_real = self.discriminator(inputs.contiguous())
-            logits_fake = self.discriminator(reconstructions.contiguous().detach())
+            # one pass over [real ; fake]: the discriminator has no batch-coupled op (LayerNorm and attention are per
+            # clip), so this equals the reference's two calls (:417-424) and halves the launches
+            nb = inputs.shape[0]
+            logits = self.discriminator(torch.cat([inputs, reconstructions.detach()], dim=0))
+            logits_real, logits_fake = logits[:nb], logits[nb:]
             if self.lecam_weight > 0.0:
                 lecam_loss = self.lecam_weight * lecam_reg(real_pred=logits_real.mean(), fake_pred=logits_fake.mean(),
                                                            ema_real_pred=self.lecam_ema_real, ema_fake_pred=self.lecam_ema_fake)
