@@ -215,10 +215,11 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt192_kernel<VT_EPI_BF16> (qkv fwd + fc1/proj/qkv dgrad)", "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
                                "per_shape": per, "whole_step_frac": round(clips_s / world * f_clip / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (other ranks would sit in teardown meanwhile)
             res["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 may still be replaying the dominant kernel for `roofline`: nobody tears the group down early
         dist.destroy_process_group()
 
 
