@@ -13,7 +13,7 @@ def load(d, name):
     f = glob.glob(f"$R/gpurun_out/{d}/*/*counter_collection.csv")[0]
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "gemm_nt192_kernel<0>" in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if "gemm_nt192_kernel<0" in r["Kernel_Name"] and r["Counter_Name"] == name:
             out[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
     return out
 fe, wr = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")

@@ -164,9 +164,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         for (int k = 0; k < G::P; ++k) stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, tile * TK, dst, k, tid, wave);
     };
     // make tile `nx` visible to every wave (its DMA landed everywhere) and recycle the buffer of tile nx-1, whose
-    // fragments every wave already holds in registers, for tile nx-1+NST.  Its P DMA pieces are issued between the
-    // first MFMA rows of the following tile body (VT_DMA), so the matrix pipe restarts right behind the barrier
-    // instead of behind ~150 cycles of DMA issue.  With 3 stages one younger tile stays in flight across the barrier.
+    // fragments every wave already holds in registers, for tile nx-1+NST.  Its P DMA pieces are issued as one block in
+    // the middle of the following tile body (VT_DMA_ALL), where the partner wave of the SIMD keeps the matrix pipe
+    // busy.  With 3 stages one younger tile stays in flight across the barrier.
     auto sync_for = [&](int nx) {
         if (G::NST == 3 && nx + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::P) : "memory");
         else wait_vmcnt0();

@@ -147,9 +147,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 struct ReduceOuts {
     float* o[3];
 };
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nslab, int64_t slab_stride, int width,
-                                                               ReduceOuts outs) {
-    __shared__ float red[8][33];
+template <int NL>  // slab lanes per column: 8 (256 threads) or 32 (1024 threads, for the 512-slab LayerNorm partials)
+__global__ __launch_bounds__(32 * NL) void reduce_partials_kernel(const float* __restrict__ partial, int nslab, int64_t slab_stride, int width,
+                                                                   ReduceOuts outs) {
+    __shared__ float red[NL][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     const int w = blockIdx.y;
@@ -157,16 +158,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (c < width) {
         const float* p = partial + (int64_t)w * width + c;
 #pragma unroll 4
-        for (int i = ty; i < nslab; i += 8) s += p[(int64_t)i * slab_stride];
+        for (int i = ty; i < nslab; i += NL) s += p[(int64_t)i * slab_stride];
     }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < width) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        for (int k = 0; k < NL; ++k) t += red[k][tx];
         outs.o[w][c] = t;
     }
+}
+
+static void launch_reduce_partials(const float* partial, int nslab, int64_t slab_stride, int width, int nout, const ReduceOuts& ro, hipStream_t s) {
+    const dim3 grid((width + 31) / 32, nout);
+    if (nslab >= 128) hipLaunchKernelGGL(reduce_partials_kernel<32>, grid, dim3(1024), 0, s, partial, nslab, slab_stride, width, ro);
+    else hipLaunchKernelGGL(reduce_partials_kernel<8>, grid, dim3(256), 0, s, partial, nslab, slab_stride, width, ro);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,7 +345,7 @@ extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xm
     VT_CHECK_LAUNCH("vt_layernorm_bwd");
     ReduceOuts ro;
     ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = dxsum;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 31) / 32, dxsum ? 3 : 2), dim3(256), 0, s, part, grid, (int64_t)3 * dim, dim, ro);
+    launch_reduce_partials(part, grid, (int64_t)3 * dim, dim, dxsum ? 3 : 2, ro, s);
     VT_CHECK_LAUNCH("vt_layernorm_bwd/reduce");
     return VT_OK;
 }
@@ -361,7 +368,7 @@ extern "C" int vt_colsum(const void* src, int32_t src_is_bf16, int64_t ld, vtRow
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ld, to_map(map), rows, width, rps, (float*)workspace);
     ReduceOuts ro;
     ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32, 1), dim3(256), 0, s, (const float*)workspace, slabs, (int64_t)width, width, ro);
+    launch_reduce_partials((const float*)workspace, slabs, (int64_t)width, width, 1, ro, s);
     VT_CHECK_LAUNCH("vt_colsum");
     return VT_OK;
 }
@@ -379,7 +386,7 @@ extern "C" int vt_sum_slabs(const float* slabs, int32_t nslab, int64_t slab_stri
     VT_CHECK_ARG(slabs && out && nslab > 0 && width > 0, "vt_sum_slabs: bad arguments");
     ReduceOuts ro;
     ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, slabs, nslab, slab_stride, width, ro);
+    launch_reduce_partials(slabs, nslab, slab_stride, width, 1, ro, (hipStream_t)stream);
     VT_CHECK_LAUNCH("vt_sum_slabs");
     return VT_OK;
 }
