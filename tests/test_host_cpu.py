@@ -257,3 +257,25 @@ def test_model_deepcopy_and_requires_grad_helpers():
     assert all(p.requires_grad == (id(p) not in dec) for p in m.parameters())
     m.others_requires_grad_(False)
     assert not any(p.requires_grad for p in m.parameters())
+
+
+def test_plain_c_client_links_against_the_c_abi(tmp_path):
+    """gcc (not hipcc, not C++) compiles a client of include/vt_hip.h and links libvt_hip.so: the boundary is a C ABI."""
+    import shutil
+    import subprocess
+    from video_tokenizer_amd import build as vt_build
+    lib = vt_build.build()
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(lib)
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+           "-o", exe, "-L", libdir, "-lvt_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    assert shutil.which("gcc"), "gcc missing"
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "abi 2"
+    assert lines[1].startswith("gemm_nt rc -1 msg vt_gemm_nt: null operand")
+    assert lines[2].startswith("create rc 0 stages 5 ws ") and int(lines[2].split()[-1]) > 1 << 20
+    assert lines[3].startswith("bad create rc -1") and "head_dim" in lines[3]
+    assert lines[4].startswith("stack rc 0 ws ")
