@@ -241,3 +241,48 @@ def test_discriminator_at_the_shipped_size():
     x2 = x.detach().clone().requires_grad_(True)
     (3.0 * m(x2)).sum().backward()
     assert rel(x2.grad, 3.0 * x.grad) < 2e-2
+
+
+def test_gan_training_loop_tokenizer_plus_discriminator():
+    """The schedule of trainers/larp_tokenizer_trainer.py:263-345 on this build's modules: tokenizer forward; every
+    d_update_freq-th step the discriminator update on the detached reconstruction; then the generator loss
+    (pixel + g_loss through the frozen discriminator + loss_q) -> backward through discriminator AND tokenizer engine ->
+    fused Adam.  A fixed batch must be reconstructed better after a few steps and everything stays finite."""
+    import video_tokenizer_amd as vt
+    from tests.test_model_gpu import build
+    from video_tokenizer_amd.optim import FusedAdam
+    cfg = O.make_cfg("tiny", frame_num=4)
+    model, _ = build(cfg, stochastic=True)
+    model.train()
+    c = dict(hidden=128, n_heads=4, n_layers=2, input_size=cfg["input_size"], frame_num=cfg["frame_num"], pt=2, ps=8)
+    lm = vt.make({"name": "lpips_disc_loss", "args": dict(
+        disc_type="transformer", disc_start=0, disc_self_start=-1, pixelloss_weight=1.0, perceptual_weight=0.0, pixel_loss="l1",
+        lecam_weight=0.001, disc_loss="ns_smooth", disc_weight=0.3, r1_gp_weight=0.0, d_update_freq=2, spectral_norm=False,
+        disc_tran_hidden_size=c["hidden"], disc_tran_n_heads=c["n_heads"], disc_tran_n_layers=c["n_layers"],
+        disc_tran_temporal_patch_size=c["pt"], disc_tran_patch_size=c["ps"], input_spatial_size=c["input_size"], frame_num=c["frame_num"])}).cuda()
+    opt_g = FusedAdam(model, lr=2e-3, betas=(0.5, 0.9))
+    opt_d = torch.optim.Adam(lm.trainable_parameters(), lr=1e-4, betas=(0.5, 0.9))
+    data = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 81)).cuda()
+    rec, d_losses = [], []
+    for step in range(8):
+        out = model(data)
+        pred = out["pred_frames"]
+        if step % lm.d_update_freq == 0:
+            lm.trainable_requires_grad_(True)
+            d_loss, d_info, _ = lm(data, pred.detach(), global_step=step, for_discriminator=True)
+            opt_d.zero_grad()
+            d_loss.backward()
+            opt_d.step()
+            d_losses.append(float(d_loss))
+        lm.trainable_requires_grad_(False)
+        loss, info, _ = lm(data, pred, global_step=step, for_discriminator=False)
+        loss = loss + 0.1 * out["loss_q"]
+        opt_g.zero_grad(set_to_none=True)
+        loss.backward()
+        opt_g.step()
+        rec.append(float(info["rec_loss"]))
+        assert torch.isfinite(loss) and all(torch.isfinite(v).all() for v in info.values() if torch.is_tensor(v))
+    torch.cuda.synchronize()
+    assert rec[-1] < rec[0], rec                      # the generator learns the fixed batch
+    assert all(np.isfinite(d_losses)) and len(d_losses) == 4
+    assert all(q.grad is None or torch.isfinite(q.grad).all() for q in lm.discriminator.parameters())
