@@ -91,6 +91,49 @@ def measured_traffic():
         return int(json.load(f)["traffic_bytes_per_launch_mean"])
 
 
+def gan_step(vt, model, x, steps, warmup):
+    """Secondary figure: the trainer's step with its GAN branch (larp_tokenizer_trainer.py:263-345) --
+    tokenizer forward, discriminator update on the detached reconstruction every d_update_freq-th step, generator loss
+    (L1 + 0.3 * ns_g_loss through the frozen discriminator + 0.1 * loss_q), backward through discriminator and tokenizer.
+    LPIPS is off (its VGG weights are not available offline), no optimizer steps: comparable to the headline step."""
+    lm = vt.make({"name": "lpips_disc_loss", "args": dict(
+        disc_type="transformer", disc_start=0, disc_self_start=-1, pixelloss_weight=1.0, perceptual_weight=0.0, pixel_loss="l1",
+        lecam_weight=0.001, disc_loss="ns_smooth", disc_weight=0.3, r1_gp_weight=0.0, d_update_freq=5, spectral_norm=False,
+        disc_tran_hidden_size=384, disc_tran_n_heads=12, disc_tran_n_layers=8, disc_tran_temporal_patch_size=4, disc_tran_patch_size=8,
+        input_spatial_size=x.shape[-1], frame_num=x.shape[2])}).to(x.device)
+    it = [0]
+
+    def step():
+        out = model(x)
+        pred = out["pred_frames"]
+        if it[0] % lm.d_update_freq == 0:
+            lm.trainable_requires_grad_(True)
+            d_loss, _, _ = lm(x, pred.detach(), global_step=it[0], for_discriminator=True)
+            for q in lm.discriminator.parameters():
+                q.grad = None
+            d_loss.backward()
+        lm.trainable_requires_grad_(False)
+        loss, _, _ = lm(x, pred, global_step=it[0], for_discriminator=False)
+        loss = loss + 0.1 * out["loss_q"]
+        for q in model.parameters():
+            q.grad = None
+        loss.backward()
+        it[0] += 1
+
+    n = max(steps, 10) // 5 * 5          # whole d_update_freq periods
+    for _ in range(max(warmup, 5)):
+        step()
+    torch.cuda.synchronize()
+    it[0] = 0
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(x.shape[0] / dt, 2), "steps": n,
+            "what": "tokenizer fwd+bwd + generator-side pass through the discriminator every step + discriminator update every 5th step; LPIPS off"}
+
+
 def cpu_baseline(c, sd_seed=7):
     """The oracle (CPU restatement, fp32, reference semantics) timed on this host's cores: ONE clip of the
     same workload, forward + backward, stochastic=False index path (multinomial is not the cost)."""
@@ -122,6 +165,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
                     help="also step Adam(lr 1e-4, betas (0.5,0.9)) inside the timed step: 'fused' = vt_adam_step over flat buffers")
+    ap.add_argument("--gan", action="store_true",
+                    help="also time the step with the GAN branch of the trainer (discriminator of cfgs/larp_tokenizer.yaml:113-136, LPIPS off): "
+                         "reported under the extra key 'gan_step'; the headline metric is unchanged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -210,6 +256,8 @@ def main():
             "model_tflops_per_gpu": round(clips_s / world * f_clip / 1e12, 1),
             "attention_gemm_tflops_per_gpu": round(clips_s / world * f_attn / 1e12, 1),
         }
+        if a.gan and world == 1:
+            res["gan_step"] = gan_step(vt, model, x, a.steps, a.warmup)
         if not a.no_roofline:
             ach, per, _ = time_dominant_kernel(B, c)
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt192_kernel<VT_EPI_BF16> (qkv fwd + fc1/proj/qkv dgrad)", "achieved": round(ach, 1),
