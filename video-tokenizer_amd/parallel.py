@@ -24,6 +24,9 @@ class GradReducer:
         self.pending = None  # (flat, lo, hi)
         self.comm_stream = None
         self.launched = []   # (lo, hi) ranges reduced in this backward (for tests/inspection)
+        # RCCL averages inside the collective (ncclAvg): saves a read-modify-write pass over the 694 MB of gradients that
+        # would compete with the backward kernels for HBM; gloo (CPU tests) has no AVG, so sum then scale there
+        self.use_avg = dist.get_backend(process_group) == "nccl"
 
     def _launch(self, flat, lo, hi):
         if hi <= lo:
@@ -36,8 +39,11 @@ class GradReducer:
             ev.record(torch.cuda.current_stream(flat.device))  # slice fully written by kernels enqueued so far
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
-                view.mul_(1.0 / self.world)
+                if self.use_avg:
+                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+                    view.mul_(1.0 / self.world)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
             view.mul_(1.0 / self.world)
