@@ -57,6 +57,25 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t 
     }
 }
 
+// Full (unclamped) tiles of the steady state: lane offsets inside a [64][HD] tile are loop invariants (stage_offsets), the
+// tile's first row is a scalar base pointer.
+template <int HD>
+__device__ __forceinline__ void stage_offsets(int64_t rs, int tid, unsigned (&off)[AG<HD>::CH / 4]) {
+    constexpr int CH = AG<HD>::CH;
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) {
+        const int slot = i * 256 + tid;
+        const int row = slot / CH;
+        const int lc = (slot % CH) ^ fsw<HD>(row);
+        off[i] = (unsigned)((row * rs + lc * 8) * 2);
+    }
+}
+template <int HD>
+__device__ __forceinline__ void stage64_full(const bf16_t* tile_row0, const unsigned (&off)[AG<HD>::CH / 4], unsigned lds, int wave) {
+#pragma unroll
+    for (int i = 0; i < AG<HD>::CH / 4; ++i) glds16_sv(tile_row0, off[i], lds + (i * 256 + wave * 64) * 16);
+}
+
 // A operand of a 32x32x16 MFMA from tile rows r0..r0+31, k-step s (16 columns)
 template <int HD>
 __device__ __forceinline__ bf16x8 rowfrag(const char* lds, int r0, int s, int lane) {
@@ -211,9 +230,15 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     // hot loop: full 64-key tiles only; a ragged last tile (L % 64 != 0) runs once, after the loop, so its masking
     // code never shares registers with the steady state
     const int nfull = (L & 63) ? nt - 1 : nt;
+    unsigned soff[AG<HD>::CH / 4];
+    stage_offsets<HD>(rs, tid, soff);
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
+        if (t + 1 < nfull) {          // next tile is a full one: scalar base + invariant lane offsets
+            const bf16_t* kt = kb + (int64_t)(t + 1) * 64 * rs;
+            stage64_full<HD>(kt, soff, sbase + (cur ^ 1) * 2 * TILE, wave);
+            stage64_full<HD>(kt + (int64_t)H * HD, soff, sbase + (cur ^ 1) * 2 * TILE + TILE, wave);
+        } else if (t + 1 < nt) {      // the ragged last tile: clamped rows
             stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
             stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
@@ -319,9 +344,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     __syncthreads();
 
     const int nfull = (L & 63) ? nt - 1 : nt;
+    unsigned soff[AG<HD>::CH / 4];
+    stage_offsets<HD>(rs, tid, soff);
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
+        if (t + 1 < nfull) {
+            const bf16_t* kt = kb + (int64_t)(t + 1) * 64 * rs;
+            stage64_full<HD>(kt, soff, sbase + (cur ^ 1) * 2 * TILE, wave);
+            stage64_full<HD>(kt + (int64_t)H * HD, soff, sbase + (cur ^ 1) * 2 * TILE + TILE, wave);
+        } else if (t + 1 < nt) {
             stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
             stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
@@ -421,10 +452,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     constexpr int BUF = 2 * TILE + 512;
     const int nt = (L + 63) / 64;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    unsigned qoff[AG<HD>::CH / 4], dooff[AG<HD>::CH / 4];
+    stage_offsets<HD>(rs, tid, qoff);
+    stage_offsets<HD>(ors, tid, dooff);
+    const int nfull_q = L / 64;        // query tiles without a ragged row
     auto stage = [&](int t, int buf) {
         const unsigned base = sbase + buf * BUF;
-        stage64<HD>(qb, rs, t * 64, L, base, tid, wave);
-        stage64<HD>(dob, ors, t * 64, L, base + TILE, tid, wave);
+        if (t < nfull_q) {
+            stage64_full<HD>(qb + (int64_t)t * 64 * rs, qoff, base, wave);
+            stage64_full<HD>(dob + (int64_t)t * 64 * ors, dooff, base + TILE, wave);
+        } else {
+            stage64<HD>(qb, rs, t * 64, L, base, tid, wave);
+            stage64<HD>(dob, ors, t * 64, L, base + TILE, tid, wave);
+        }
         if (wave < 2) {  // wave 0: lse2[64], wave 1: delta[64] by 4-byte LDS-DMA (rows past L clamped; masked at use)
             int qq = t * 64 + lane;
             qq = qq < L ? qq : L - 1;

@@ -77,6 +77,21 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_byte_ad
         : "v"(gsrc), "s"(lds_byte_addr)
         : "memory");
 }
+// 16-B LDS-DMA with a WAVE-UNIFORM 64-bit base (SGPR pair) and a per-lane 32-bit byte offset.  A streaming kernel computes
+// the lane offsets once; per tile it only advances the scalar base, so staging costs no per-lane address arithmetic
+// (the 64-bit multiply-adds of glds16_asm were 16 % of the attention forward, tools ablation in DESIGN.md).
+__device__ __forceinline__ void glds16_sv(const void* base_uniform, unsigned lane_byte_off, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_byte_off), "s"(base_uniform), "s"(lds_byte_addr)
+        : "memory");
+}
 // drain this wave's LDS-DMA before a barrier that publishes the staged tile (the compiler does not see asm DMAs)
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(VT_LDS const char*)p; }

@@ -58,21 +58,32 @@ struct NTGeo {
     static constexpr int P = PA + PB;
 };
 
-// one of the P 16-B-per-lane DMA pieces of a K-tile: pieces 0..PA-1 = A rows, PA..P-1 = B rows
+// The P 16-B-per-lane DMA pieces of a K-tile (pieces 0..PA-1 = A rows, PA..P-1 = B rows).  A lane's byte offset inside
+// its operand's [tile rows][K] panel does not depend on the K-tile (row clamp and swizzle are per row), so it is computed
+// once (nt192_piece_offsets) and every K-tile costs only the scalar advance of the two panel pointers: glds16_sv.
 template <int WN>
-__device__ __forceinline__ void stage_piece_nt192(const bf16_t* __restrict__ A, int64_t lda, int m0, int M, const bf16_t* __restrict__ B,
-                                                  int64_t ldb, int n0, int N, int k0, unsigned lds, int piece, int tid, int wave) {
+__device__ __forceinline__ void nt192_piece_offsets(int64_t lda, int m0, int M, int64_t ldb, int n0, int N, int tid, unsigned (&off)[NTGeo<WN>::P]) {
+    using G = NTGeo<WN>;
+#pragma unroll
+    for (int piece = 0; piece < G::P; ++piece) {
+        const bool isA = piece < G::PA;
+        const int i = isA ? piece : piece - G::PA;
+        const int slot = i * G::THREADS + tid;
+        const int row = slot >> 3;
+        const int lc = (slot & 7) ^ ((row >> 1) & 7);
+        const int r0 = isA ? m0 : n0, lim = isA ? M : N;
+        int gr = r0 + row;
+        gr = (gr < lim ? gr : lim - 1) - r0;          // rows past the matrix re-read its last row (never stored)
+        off[piece] = (unsigned)((gr * (isA ? lda : ldb) + lc * 8) * 2);
+    }
+}
+template <int WN>
+__device__ __forceinline__ void nt192_stage_piece(const bf16_t* a_panel, const bf16_t* b_panel, const unsigned (&off)[NTGeo<WN>::P], unsigned lds,
+                                                  int piece, int wave) {
     using G = NTGeo<WN>;
     const bool isA = piece < G::PA;
     const int i = isA ? piece : piece - G::PA;
-    const int slot = i * G::THREADS + tid;
-    const int row = slot >> 3;
-    const int lc = (slot & 7) ^ ((row >> 1) & 7);
-    int gr = (isA ? m0 : n0) + row;
-    const int lim = isA ? M : N;
-    gr = gr < lim ? gr : lim - 1;
-    const bf16_t* g = isA ? A + (int64_t)gr * lda : B + (int64_t)gr * ldb;
-    glds16_asm(g + k0 + lc * 8, lds + (isA ? 0 : G::OPA) + (i * G::THREADS + wave * 64) * 16);
+    glds16_sv(isA ? a_panel : b_panel, off[piece], lds + (isA ? 0 : G::OPA) + (i * G::THREADS + wave * 64) * 16);
 }
 
 template <int EPI, int WN>
@@ -124,8 +135,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     // compute from set C (a0,b0 = k-step 0; a1,b1 = k-step 1) while prefetching the tile at LDS address `nb` into set N
 #define VT_DMA_ALL                                                                                                   \
     if (dma_tile >= 0) {                                                                                             \
-        _Pragma("unroll") for (int k_ = 0; k_ < G::P; ++k_)                                                          \
-            stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, dma_tile * TK, dma_dst, k_, tid, wave);     \
+        const bf16_t* ap_ = Apanel + dma_tile * TK;                                                                  \
+        const bf16_t* bp_ = Bpanel + dma_tile * TK;                                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < G::P; ++k_) nt192_stage_piece<WN>(ap_, bp_, poff, dma_dst, k_, wave); \
     }
 #define VT_STEP(Ca0, Cb0, Ca1, Cb1, Na0, Nb0, Na1, Nb1, nb, pf)                                                      \
     {                                                                                                                \
@@ -158,10 +170,14 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
+    unsigned poff[G::P];
+    nt192_piece_offsets<WN>(p.lda, m0, p.M, p.ldb, n0, p.N, tid, poff);
+    const bf16_t* Apanel = A + (int64_t)m0 * p.lda;   // wave-uniform: rows m0.. of A / n0.. of B, K-tile 0
+    const bf16_t* Bpanel = B + (int64_t)n0 * p.ldb;
     auto issue_tile = [&](int tile) {  // LDS-DMA of K-tile `tile` into ring buffer tile % NST
         const unsigned dst = sbase + (tile % G::NST) * G::STAGE;
 #pragma unroll
-        for (int k = 0; k < G::P; ++k) stage_piece_nt192<WN>(A, p.lda, m0, p.M, B, p.ldb, n0, p.N, tile * TK, dst, k, tid, wave);
+        for (int k = 0; k < G::P; ++k) nt192_stage_piece<WN>(Apanel + tile * TK, Bpanel + tile * TK, poff, dst, k, wave);
     };
     // make tile `nx` visible to every wave (its DMA landed everywhere) and recycle the buffer of tile nx-1, whose
     // fragments every wave already holds in registers, for tile nx-1+NST.  Its P DMA pieces are issued as one block in
@@ -325,7 +341,8 @@ struct TN192Args {
 // [64 m-rows][192 cols] bf16 image, 384-B rows = 24 chunks; physical chunk = (lc & ~7) | ((lc & 7) ^ f(row))
 __device__ __forceinline__ int swz_tn192(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
 
-__device__ __forceinline__ void stage_tn192(const bf16_t* __restrict__ g, int64_t ld, int m0, int c0, int ncols, unsigned lds, int tid, int wave) {
+// lane byte offsets of the 3 DMA pieces inside a [64 m-rows][ncols] slab starting at column c0 (invariant over K-tiles)
+__device__ __forceinline__ void tn192_piece_offsets(int64_t ld, int c0, int ncols, int tid, unsigned (&off)[3]) {
     const int maxchunk = (ncols >> 3) - 1;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -335,8 +352,12 @@ __device__ __forceinline__ void stage_tn192(const bf16_t* __restrict__ g, int64_
         const int lc = (pc & ~7) | ((pc & 7) ^ swz_tn192(row));
         int gc = (c0 >> 3) + lc;
         gc = gc < maxchunk ? gc : maxchunk;
-        glds16_asm(g + (int64_t)(m0 + row) * ld + gc * 8, lds + (i * 512 + wave * 64) * 16);
+        off[i] = (unsigned)((row * ld + gc * 8) * 2);
     }
+}
+__device__ __forceinline__ void stage_tn192(const bf16_t* slab_row0, const unsigned (&off)[3], unsigned lds, int wave) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) glds16_sv(slab_row0, off[i], lds + (i * 512 + wave * 64) * 16);
 }
 
 __device__ __forceinline__ bf16x8 frag_tn192(const char* lds, int col, int kb, int lane) {
@@ -377,11 +398,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
 
     const int nt = p.M / TK;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    stage_tn192(A, p.lda, 0, p0, p.P, sbase, tid, wave);
-    stage_tn192(B, p.ldb, 0, q0, p.Q, sbase + OP_BYTES, tid, wave);
+    unsigned aoff[3], boff[3];
+    tn192_piece_offsets(p.lda, p0, p.P, tid, aoff);
+    tn192_piece_offsets(p.ldb, q0, p.Q, tid, boff);
+    stage_tn192(A, aoff, sbase, wave);
+    stage_tn192(B, boff, sbase + OP_BYTES, wave);
     if (nt > 1) {
-        stage_tn192(A, p.lda, TK, p0, p.P, sbase + STAGE_BYTES, tid, wave);
-        stage_tn192(B, p.ldb, TK, q0, p.Q, sbase + STAGE_BYTES + OP_BYTES, tid, wave);
+        stage_tn192(A + (int64_t)TK * p.lda, aoff, sbase + STAGE_BYTES, wave);
+        stage_tn192(B + (int64_t)TK * p.ldb, boff, sbase + STAGE_BYTES + OP_BYTES, wave);
     }
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
@@ -389,8 +413,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
         raw_barrier();
         if (t + 2 < nt) {
             int nx = cur + 2; nx = nx >= NSTAGE ? nx - NSTAGE : nx;
-            stage_tn192(A, p.lda, (t + 2) * TK, p0, p.P, sbase + nx * STAGE_BYTES, tid, wave);
-            stage_tn192(B, p.ldb, (t + 2) * TK, q0, p.Q, sbase + nx * STAGE_BYTES + OP_BYTES, tid, wave);
+            stage_tn192(A + (int64_t)(t + 2) * TK * p.lda, aoff, sbase + nx * STAGE_BYTES, wave);
+            stage_tn192(B + (int64_t)(t + 2) * TK * p.ldb, boff, sbase + nx * STAGE_BYTES + OP_BYTES, wave);
         }
         const char* la = smem + cur * STAGE_BYTES;
         const char* lb = la + OP_BYTES;
