@@ -17,6 +17,8 @@ def lib():
         _lib.vq_normalize_rows.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, f32p, f32p, ctypes.c_float]
         _lib.vq_search.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float, i64p, f32p]
         _lib.vq_gather.argtypes = [f32p, f32p, i64p, ctypes.c_int64, ctypes.c_int, f32p, f32p, ctypes.POINTER(ctypes.c_double)]
+        _lib.vq_codebook_grad.argtypes = [f32p, f32p, f32p, i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                          ctypes.c_int64, f32p]
     return _lib
 
 
@@ -69,3 +71,18 @@ def vq_forward(z_in, emb_weight, mode, l2_normalized=True, temperature=0.03, bet
     mse = tot / z.size
     return {"z": z, "emb": e, "idx": idx, "score": sc, "q": q, "regularized_z": rz,
             "loss_commit": mse, "loss_codebook": mse, "loss_q": beta * mse + codebook_w * mse}
+
+
+def codebook_grad(zn, e, wnorm, idx, s_b, normalize=True):
+    """dW in the HIP path's summation order (vt_vq_backward): slabs of cb_slab_len(N) tokens, sequential inside."""
+    zn = np.ascontiguousarray(zn, dtype=np.float32)
+    e = np.ascontiguousarray(e, dtype=np.float32)
+    wnorm = np.ascontiguousarray(wnorm, dtype=np.float32)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n, d = zn.shape
+    ns = min(32, max(1, (n + 511) // 512))
+    slab = ((n + ns - 1) // ns + 63) // 64 * 64
+    out = np.empty_like(e)
+    lib().vq_codebook_grad(_p(zn, ctypes.c_float), _p(e, ctypes.c_float), _p(wnorm, ctypes.c_float), _p(idx, ctypes.c_int64), n, e.shape[0], d,
+                           np.float32(s_b), int(normalize), slab, _p(out, ctypes.c_float))
+    return out

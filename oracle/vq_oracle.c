@@ -91,3 +91,47 @@ void vq_gather(const float *z, const float *e, const int64_t *idx, int64_t n, in
     }
     *sq_sum_out = tot;
 }
+
+/* Dense codebook gradient in the summation order of the HIP path (vt_vq.hip: vq_bwd_codebook_mfma_kernel + _finalize):
+ * autograd of F.embedding(sparse=False) through F.normalize (models/bottleneck.py:292-307):
+ *   de[k] = s_b * sum_n [idx[n] == k] (e_k - z_n),   dW[k] = (de - e (e.de)) / |w_k|
+ * with every slab of `slab_len` tokens summed as a sequential fp32 chain over ascending n (what the exact-fp32 MFMA
+ * does with a one-hot operand), the slabs added in ascending order, e.de reduced by a 32-lane xor butterfly
+ * (16, 8, 4, 2, 1) and de - e (e.de) formed by one fused multiply-add.  TEST INFRASTRUCTURE ONLY. */
+void vq_codebook_grad(const float *zn, const float *e, const float *wnorm, const int64_t *idx, int64_t n, int64_t k_codes,
+                      int d, float s_b, int normalize, int64_t slab_len, float *dW) {
+    int64_t nslab = (n + slab_len - 1) / slab_len;
+    for (int64_t k = 0; k < k_codes; ++k) {
+        float de[32], lanes[32];
+        for (int j = 0; j < 32; ++j) de[j] = 0.0f;
+        for (int64_t s = 0; s < nslab; ++s) {
+            float part[32];
+            for (int j = 0; j < 32; ++j) part[j] = 0.0f;
+            int64_t hi = (s + 1) * slab_len < n ? (s + 1) * slab_len : n;
+            for (int64_t t = s * slab_len; t < hi; ++t)
+                if (idx[t] == k)
+                    for (int j = 0; j < d; ++j) {
+                        volatile float diff = e[k * d + j] - zn[t * d + j];
+                        part[j] = part[j] + diff;
+                    }
+            for (int j = 0; j < d; ++j) de[j] = de[j] + part[j];
+        }
+        for (int j = 0; j < 32; ++j) {
+            de[j] = j < d ? de[j] * s_b : 0.0f;
+            volatile float prod = j < d ? e[k * d + j] * de[j] : 0.0f;
+            lanes[j] = prod;
+        }
+        for (int o = 16; o > 0; o >>= 1) {
+            float nxt[32];
+            for (int j = 0; j < 32; ++j) nxt[j] = lanes[j] + lanes[j ^ o];
+            for (int j = 0; j < 32; ++j) lanes[j] = nxt[j];
+        }
+        for (int j = 0; j < d; ++j) {
+            if (normalize) {
+                dW[k * d + j] = fmaf(-e[k * d + j], lanes[j], de[j]) / wnorm[k];   /* one rounding, as the kernel's fmaf */
+            } else {
+                dW[k * d + j] = de[j];
+            }
+        }
+    }
+}

@@ -323,6 +323,25 @@ def test_vq_backward_matches_reference_grads(hip, case, golden_dir):
     np.testing.assert_allclose(dW.cpu().numpy(), f["dE"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,K,d,collapse", [(700, 512, 24, False), (2048, 1024, 16, False), (1500, 256, 24, True)])
+def test_vq_codebook_gradient_bit_exact_vs_c_oracle(hip, N, K, d, collapse):
+    """dW = OneHot^T (Q - Z) on the exact-fp32 MFMA: equal, bit for bit, to the C restatement of its summation order --
+    also when most tokens sit on a handful of codes (the regime the kernel was rewritten for)."""
+    W = gen.kaiming_uniform_codebook(K, d, 301)
+    z = gen.normal((N, d), 302)
+    if collapse:
+        z[: N - 100] = W[7] + 0.05 * z[: N - 100]            # most tokens next to code 7
+    o = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 0)
+    gs = np.array([0.7, 0.0, 0.3], dtype=np.float32)
+    dz, _, dW = hip.vq_backward(None, torch.from_numpy(gs).cuda(), o)
+    torch.cuda.synchronize()
+    s_b = np.float32(np.float32(gs[0] * np.float32(1.0) + gs[2]) * np.float32(2.0)) / np.float32(np.float32(N) * np.float32(d))
+    ref = vq_c.codebook_grad(o["zn"].cpu().numpy(), o["E"].cpu().numpy(), o["wnorm"].cpu().numpy(), o["idx"].cpu().numpy(), s_b)
+    if collapse:
+        assert np.bincount(o["idx"].cpu().numpy(), minlength=K).max() > N // 2
+    assert np.array_equal(dW.cpu().numpy(), ref)
+
+
 def test_vq_stochastic_mode_matches_softmax_distribution(hip):
     """mode 2 has no bit-exact oracle (torch.multinomial CPU != GPU): chi-square of the sampled index
     frequencies of ONE token replicated N times against softmax(cos/tau) from the oracle."""

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_mfma_kernel(const float* 
 __global__ __launch_bounds__(256) void vq_bwd_codebook_finalize(const float* __restrict__ part, int nslab, const float* __restrict__ gscal,
                                                                  float cbw, const float* __restrict__ E, const float* __restrict__ wnorm,
                                                                  int N, int K, int d, int normalize, float* __restrict__ dW) {
+#pragma clang fp contract(off)   // every rounding below is spelled out: the product e*de must not fuse into the first butterfly add
     const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int j = threadIdx.x & 31;
     const float s_b = (gscal ? gscal[0] * cbw + gscal[2] : 0.f) * 2.0f / ((float)N * (float)d);
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(256) void vq_bwd_codebook_finalize(const float* __r
     float dot = e * de;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-    if (k < K && j < d) dW[(int64_t)k * d + j] = normalize ? (de - e * dot) / wnorm[k] : de;
+    // one fused multiply-add, written out so the order is defined: the oracle restates it bit for bit (oracle/vq_oracle.c)
+    if (k < K && j < d) dW[(int64_t)k * d + j] = normalize ? fmaf(-e, dot, de) / wnorm[k] : de;
 }
 
 static inline int cb_slabs(int N) {
