@@ -153,3 +153,19 @@ def test_tiny_forward_backward_runs_and_emulation_is_close():
     assert a["bottleneck_rep"].shape == (2, cfg["bottleneck_token_num"])
     rel = (a["pred_frames"] - e["pred_frames"]).abs().max() / a["pred_frames"].abs().max()
     assert rel < 0.08, rel
+
+
+@pytest.mark.parametrize("case", vq_cases()[:2])
+def test_c_oracle_codebook_gradient_matches_reference_autograd(case, golden_dir):
+    """oracle/vq_oracle.c::vq_codebook_grad (the summation order the HIP kernel is bit-exact against) reproduces the dE the
+    reference's autograd produced for the same inputs (tests/golden/make_golden.py: upstream gradient 0.7 on loss_q)."""
+    (b, n), K, d, seed = case
+    f = np.load(f"{golden_dir}/vq_N{b * n}_K{K}_d{d}_L.npz")
+    W = gen.kaiming_uniform_codebook(K, d, seed)
+    z = gen.normal((b * n, d), seed + 1000)
+    zn, _ = vq_c.normalize_rows(z)
+    E, wn = vq_c.normalize_rows(W)
+    idx = f["idx"].reshape(-1).astype(np.int64)
+    s_b = np.float32(np.float32(0.7) * np.float32(2.0)) / np.float32(np.float32(b * n) * np.float32(d))
+    dW = vq_c.codebook_grad(zn, E, wn, idx, s_b)
+    np.testing.assert_allclose(dW, f["dE"], rtol=1e-4, atol=1e-6)
