@@ -145,6 +145,13 @@ int vt_assemble_rows(float* dst, int64_t seq, int64_t off, int32_t batch, int32_
 /* fp32 master weight W[N,K] -> bf16 W[N,ldd] and/or bf16 W^T[K,lddT]; packed row r = W[row_perm[r]] */
 int vt_pack_weight(const float* w, int32_t N, int32_t K, const int32_t* row_perm, void* wb, int64_t ldd, void* wt,
                    int64_t lddT, vtStream stream);
+/* the same for many weights at once (after an optimizer step every bf16 operand copy is refreshed); jobs is a host array */
+#define VT_PACK_MAX_GROUP 32
+typedef struct {
+    const float* w; int32_t N, K; const int32_t* row_perm;
+    void* wb; int64_t ldd; void* wt; int64_t lddT;
+} vtPackJob;
+int vt_pack_weights_grouped(const vtPackJob* jobs_host, int32_t n_jobs, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * (T,H,W) patchify / unpatchify.  Patch-row columns are in (c,dt,dy,dx) order == Conv3d weight

@@ -382,3 +382,28 @@ def test_gemm_nt_dgelu_fused_column_sums(hip, M, N, K, variant):
         np.testing.assert_allclose(part.sum(0).cpu().numpy(), hip.colsum(out).cpu().numpy(), rtol=1e-5, atol=1e-3)
     finally:
         hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")
+
+
+def test_pack_weights_grouped_equals_single_packs(hip):
+    """vt_pack_weights_grouped (all bf16 operand copies of the model in a few launches) == vt_pack_weight one by one"""
+    import ctypes
+    shapes = [(768, 768), (2304, 768), (24, 768), (768, 24), (100, 36)] * 8     # 40 jobs: two grouped launches
+    ws = [torch.from_numpy(_rand(sh, 400 + i)).cuda() for i, sh in enumerate(shapes)]
+    perm = torch.randperm(100).to(torch.int32).cuda()
+    jobs = (hip.PackJob * len(shapes))()
+    outs = []
+    for i, (w, (N, K)) in enumerate(zip(ws, shapes)):
+        wb = torch.zeros(N, K + 8, device="cuda", dtype=torch.bfloat16)
+        wt = torch.zeros(K, N + 8, device="cuda", dtype=torch.bfloat16) if i % 3 else None
+        rp = perm if (N == 100) else None
+        j = jobs[i]
+        j.w, j.N, j.K, j.row_perm = w.data_ptr(), N, K, (rp.data_ptr() if rp is not None else None)
+        j.wb, j.ldd, j.wt, j.lddT = wb.data_ptr(), K + 8, (wt.data_ptr() if wt is not None else None), N + 8
+        outs.append((wb, wt, rp))
+    hip.check(hip.lib().vt_pack_weights_grouped(jobs, len(shapes), hip.stream()), "vt_pack_weights_grouped")
+    torch.cuda.synchronize()
+    for w, (N, K), (wb, wt, rp) in zip(ws, shapes, outs):
+        src = w[rp.long()] if rp is not None else w
+        assert torch.equal(wb[:, :K], src.to(torch.bfloat16)) and torch.all(wb[:, K:] == 0)
+        if wt is not None:
+            assert torch.equal(wt[:, :N], src.t().to(torch.bfloat16)) and torch.all(wt[:, N:] == 0)

@@ -210,30 +210,43 @@ extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream st
         if (rc__) return rc__; \
     } while (0)
 
-static int pack_blocks(vtTokenizer* t, const std::vector<BlockBufs>& v, const vtBlockTensors* bl, void* ws, vtStream s) {
+static vtPackJob pack_job(const float* w, int N, int K, const int32_t* perm, void* wb, int64_t ldd, void* wt, int64_t lddT) {
+    vtPackJob q;
+    q.w = w; q.N = N; q.K = K; q.row_perm = perm; q.wb = wb; q.ldd = ldd; q.wt = wt; q.lddT = lddT;
+    return q;
+}
+
+static void pack_block_jobs(vtTokenizer* t, const std::vector<BlockBufs>& v, const vtBlockTensors* bl, void* ws, std::vector<vtPackJob>& jobs) {
     const int D = t->c.D, D3 = t->D3, D4 = t->D4;
     for (size_t i = 0; i < v.size(); ++i) {
         const BlockBufs& b = v[i];
-        TRY(vt_pack_weight(bl[i].qkv_w, D3, D, nullptr, WS(void, b.qkv_wb), D, WS(void, b.qkv_wt), D3, s));
-        TRY(vt_pack_weight(bl[i].proj_w, D, D, nullptr, WS(void, b.proj_wb), D, WS(void, b.proj_wt), D, s));
-        TRY(vt_pack_weight(bl[i].fc1_w, D4, D, nullptr, WS(void, b.fc1_wb), D, WS(void, b.fc1_wt), D4, s));
-        TRY(vt_pack_weight(bl[i].fc2_w, D, D4, nullptr, WS(void, b.fc2_wb), D4, WS(void, b.fc2_wt), D, s));
+        jobs.push_back(pack_job(bl[i].qkv_w, D3, D, nullptr, WS(void, b.qkv_wb), D, WS(void, b.qkv_wt), D3));
+        jobs.push_back(pack_job(bl[i].proj_w, D, D, nullptr, WS(void, b.proj_wb), D, WS(void, b.proj_wt), D));
+        jobs.push_back(pack_job(bl[i].fc1_w, D4, D, nullptr, WS(void, b.fc1_wb), D, WS(void, b.fc1_wt), D4));
+        jobs.push_back(pack_job(bl[i].fc2_w, D, D4, nullptr, WS(void, b.fc2_wb), D4, WS(void, b.fc2_wt), D));
     }
-    return VT_OK;
+}
+
+static int pack_blocks(vtTokenizer* t, const std::vector<BlockBufs>& v, const vtBlockTensors* bl, void* ws, vtStream s) {
+    std::vector<vtPackJob> jobs;
+    pack_block_jobs(t, v, bl, ws, jobs);
+    return vt_pack_weights_grouped(jobs.data(), (int)jobs.size(), s);
 }
 
 extern "C" int vt_tokenizer_pack(vtTokenizer* t, const vtTokenizerTensors* P, void* ws, vtStream s) {
     VT_CHECK_ARG(t && P && ws && P->enc_blocks && P->dec_blocks, "vt_tokenizer_pack: null pointer");
     const vtTokenizerConfig& c = t->c;
     const int D = c.D, Kp = t->Kp;
-    TRY(vt_pack_weight(P->pe_w, D, Kp, nullptr, WS(void, t->pe_wb), Kp, nullptr, 0, s));
-    TRY(vt_pack_weight(P->in_w, c.d, D, nullptr, WS(void, t->in_wb), D, WS(void, t->in_wt), 64, s));    // [d,D] and [D,64]
-    TRY(vt_pack_weight(P->out_w, D, c.d, nullptr, WS(void, t->out_wb), 64, WS(void, t->out_wt), D, s));  // [D,64] and [64,D]
-    TRY(vt_pack_weight(P->head_w, Kp, D, WS(int32_t, t->perm), WS(void, t->head_wb), D, WS(void, t->head_wt), Kp, s));
+    std::vector<vtPackJob> jobs;   // every bf16 operand copy of the model: 4 grouped launches instead of ~100 single ones
+    jobs.push_back(pack_job(P->pe_w, D, Kp, nullptr, WS(void, t->pe_wb), Kp, nullptr, 0));
+    jobs.push_back(pack_job(P->in_w, c.d, D, nullptr, WS(void, t->in_wb), D, WS(void, t->in_wt), 64));    // [d,D] and [D,64]
+    jobs.push_back(pack_job(P->out_w, D, c.d, nullptr, WS(void, t->out_wb), 64, WS(void, t->out_wt), D));  // [D,64] and [64,D]
+    jobs.push_back(pack_job(P->head_w, Kp, D, WS(int32_t, t->perm), WS(void, t->head_wb), D, WS(void, t->head_wt), Kp));
+    pack_block_jobs(t, t->enc, P->enc_blocks, ws, jobs);
+    pack_block_jobs(t, t->dec, P->dec_blocks, ws, jobs);
+    TRY(vt_pack_weights_grouped(jobs.data(), (int)jobs.size(), s));
     hipLaunchKernelGGL(gather_f32_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)s, P->head_b, WS(int32_t, t->perm), Kp, WS(float, t->head_b_perm));
     TRY(vt_assemble_rows(WS(float, t->dec_query_sum), t->Nv, 0, 1, t->Nv, D, nullptr, P->dec_patch_query, P->dec_token_type, s));
-    TRY(pack_blocks(t, t->enc, P->enc_blocks, ws, s));
-    TRY(pack_blocks(t, t->dec, P->dec_blocks, ws, s));
     VT_CHECK_LAUNCH("vt_tokenizer_pack");
     return VT_OK;
 }

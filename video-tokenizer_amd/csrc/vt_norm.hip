@@ -295,6 +295,44 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// the same for up to VT_PACK_MAX_GROUP weights in one launch (after an optimizer step every bf16 operand copy of the
+// model is refreshed: ~100 matrices, launch-latency-bound one by one)
+struct PackGroup {
+    vtPackJob job[VT_PACK_MAX_GROUP];
+    int tile_start[VT_PACK_MAX_GROUP + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_weight_group_kernel(const PackGroup g) {
+    __shared__ float tile[32][33];
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.tile_start[j + 1]) ++j;
+    const vtPackJob& q = g.job[j];
+    const int local = blockIdx.x - g.tile_start[j];
+    const int tiles_k = (q.K + 31) / 32;
+    const int n0 = (local / tiles_k) * 32, k0 = (local % tiles_k) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    bf16_t* wb = (bf16_t*)q.wb;
+    bf16_t* wt = (bf16_t*)q.wt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + i * 8, k = k0 + tx;
+        float v = 0.f;
+        if (n < q.N && k < q.K) {
+            const int sn = q.row_perm ? q.row_perm[n] : n;
+            v = q.w[(int64_t)sn * q.K + k];
+            if (wb) wb[(int64_t)n * q.ldd + k] = f2bf(v);
+        }
+        tile[ty + i * 8][tx] = v;
+    }
+    if (!wt) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + i * 8, n = n0 + tx;
+        if (n < q.N && k < q.K) wt[(int64_t)k * q.lddT + n] = f2bf(tile[tx][ty + i * 8]);
+    }
+}
+
 }  // namespace
 
 static inline RowMap to_map(vtRowMap m) { return RowMap{m.grp, m.stride, m.off}; }
@@ -423,5 +461,24 @@ extern "C" int vt_pack_weight(const float* w, int32_t N, int32_t K, const int32_
     const dim3 grid((K + 31) / 32, (N + 31) / 32);
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, N, K, row_perm, (bf16_t*)wb, ldd, (bf16_t*)wt, lddT);
     VT_CHECK_LAUNCH("vt_pack_weight");
+    return VT_OK;
+}
+
+extern "C" int vt_pack_weights_grouped(const vtPackJob* jobs, int32_t n, vtStream stream) {
+    VT_CHECK_ARG(jobs && n > 0, "vt_pack_weights_grouped: bad arguments");
+    for (int base = 0; base < n; base += VT_PACK_MAX_GROUP) {
+        PackGroup g;
+        g.n = n - base < VT_PACK_MAX_GROUP ? n - base : VT_PACK_MAX_GROUP;
+        g.tile_start[0] = 0;
+        for (int i = 0; i < g.n; ++i) {
+            const vtPackJob& q = jobs[base + i];
+            VT_CHECK_ARG(q.w && (q.wb || q.wt) && q.N > 0 && q.K > 0, "vt_pack_weights_grouped[%d]: bad arguments", base + i);
+            VT_CHECK_ARG((!q.wb || q.ldd >= q.K) && (!q.wt || q.lddT >= q.N), "vt_pack_weights_grouped[%d]: leading dimension too small", base + i);
+            g.job[i] = q;
+            g.tile_start[i + 1] = g.tile_start[i] + ((q.N + 31) / 32) * ((q.K + 31) / 32);
+        }
+        hipLaunchKernelGGL(pack_weight_group_kernel, dim3(g.tile_start[g.n]), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    VT_CHECK_LAUNCH("vt_pack_weights_grouped");
     return VT_OK;
 }

@@ -80,6 +80,10 @@ class BlockTensors(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in BLOCK_FIELDS]
 
 
+class PackJob(ctypes.Structure):
+    _fields_ = [("w", c_vp), ("N", c_i32), ("K", c_i32), ("row_perm", c_vp), ("wb", c_vp), ("ldd", c_i64), ("wt", c_vp), ("lddT", c_i64)]
+
+
 class StackConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("B", "L", "D", "H", "depth")]
 
@@ -101,6 +105,7 @@ class TokenizerOutputs(ctypes.Structure):
 
 _TT = ctypes.POINTER(TokenizerTensors)
 ENGINE_SIGNATURES = {
+    "vt_pack_weights_grouped": (c_i32, [ctypes.POINTER(PackJob), c_i32, c_vp]),
     "vt_stack_create": (c_i32, [ctypes.POINTER(StackConfig), ctypes.POINTER(c_vp)]),
     "vt_stack_destroy": (None, [c_vp]),
     "vt_stack_workspace_bytes": (c_sz, [c_vp]),
