@@ -246,6 +246,22 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             // bf16-rounded value (autocast order).
             constexpr int UPR = G::TNW / 4;             // 8-B units per tile row
             constexpr int STRIDE = G::TNW * 2 + 8;      // bytes
+            constexpr int RL = G::THREADS / UPR;        // gelu' path: row lanes (10); RL * UPR of the threads are active
+            constexpr int NIT = (TM + RL - 1) / RL;
+            [[maybe_unused]] bf16x4 uu_pre[NIT];
+            if constexpr (EPI == VT_EPI_BF16_DGELU) {
+                // the pre-activations this thread will need after the read-back: all NIT loads go out now, so their HBM
+                // latency runs under the staging writes and the barrier instead of 20 times in the store loop
+                const int c = tid % UPR, rl = tid / UPR;
+                const int n = n0 + c * 4;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int row = it * RL + rl;
+                    const int m = m0 + row;
+                    const bool ok = rl < RL && n < p.N && row < TM && m < p.M;
+                    uu_pre[it] = ok ? *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n) : (bf16x4){f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+                }
+            }
             raw_barrier();                              // every wave is done reading the ring
             f32x4 b4[3];
 #pragma unroll
@@ -265,18 +281,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 // a thread keeps ONE 4-column group and walks the rows (48 lanes cover a 384-B row, the rest of the wave the
                 // next row), so the column sums of the rounded output -- the bias gradient of the Linear whose
                 // pre-activation is `aux` -- fall out of the epilogue instead of a separate pass over M x N
-                constexpr int RL = G::THREADS / UPR;                 // row lanes (10); RL * UPR of the threads are active
                 const int c = tid % UPR, rl = tid / UPR;
                 const int n = n0 + c * 4;
                 f32x4 cs = {0.f, 0.f, 0.f, 0.f};
                 if (rl < RL && n < p.N) {
-#pragma unroll 5
-                    for (int it = 0; it < (TM + RL - 1) / RL; ++it) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
                         const int row = it * RL + rl;
                         const int m = m0 + row;
                         if (row < TM && m < p.M) {
                             const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
-                            const bf16x4 uu = *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n);
+                            const bf16x4 uu = uu_pre[it];
                             const bf16x4 r = {f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
                                               f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))};
                             *(bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = r;
