@@ -157,9 +157,22 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
             mx = fmaxf(mx, sacc[kt][r]);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mn = fmaxf(m, mx * c);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    m = mn;
+    // Lazy rescaling: `m` is the reference point of the exponentials, not necessarily the running maximum.  It moves (and
+    // O, l are rescaled) only when some row's maximum has outgrown it by more than 2^8; until then p <= 256 instead of
+    // <= 1, harmless in fp32 sums and in bf16 P (relative precision), and lse = m + log2(l) stays exact.  After the first
+    // tiles the wave-uniform branch is almost never taken, which removes 16 packed multiplies + an exp per tile.
+    const float want = mx * c;
+    if (__builtin_amdgcn_ballot_w64(want > m + 8.0f) != 0ull) {
+        const float mn = fmaxf(m, want);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);   // m = -inf on the first tile: alpha = 0, O and l are 0 anyway
+        m = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    }
+    const float mn = m;
     float ps = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -169,13 +182,7 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
             sacc[kt][r] = p;
             ps += p;
         }
-    lsum = lsum * alpha + ps;
-    // unconditional: 16 packed multiplies; a "skip when alpha == 1" branch costs more (the compiler then copies the
-    // 32 accumulator registers around the branch every tile)
-#pragma unroll
-    for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    lsum += ps;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
