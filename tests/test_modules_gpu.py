@@ -287,3 +287,21 @@ def test_gan_training_loop_tokenizer_plus_discriminator():
     assert rec[-1] < rec[0], rec                      # the generator learns the fixed batch
     assert all(np.isfinite(d_losses)) and len(d_losses) == 4
     assert all(q.grad is None or torch.isfinite(q.grad).all() for q in lm.discriminator.parameters())
+
+
+def test_discriminator_at_config_e_size():
+    """cfgs/larp_tokenizer_large.yaml at 16x256x256: pt=4, p=8 => 4096 video tokens + cls = L 4097, head_dim 32 (BASELINE config E's GAN leg):
+    finite, input gradient present, backward linear in the upstream gradient (exact for a power-of-two factor)."""
+    import video_tokenizer_amd as vt
+    torch.manual_seed(5)
+    m = vt.TransformerDiscriminator(384, 12, 8, 256, 4, 8, 3, frame_num=16).cuda()
+    x = torch.from_numpy(gen.video_clips(1, 16, 256, 91)).cuda().requires_grad_(True)
+    y = m(x)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    assert m.video_token_num + 1 == 4097 and y.shape == (1, 1) and torch.isfinite(y).all()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    g1 = x.grad.clone()
+    x.grad = None
+    (2.0 * m(x)).sum().backward()
+    assert torch.equal(x.grad, 2.0 * g1)
