@@ -204,6 +204,14 @@ extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream st
     return VT_OK;
 }
 
+static int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        vt_set_error("device-to-device copy of %zu bytes failed", bytes);
+        return VT_ERR_LAUNCH;
+    }
+    return VT_OK;
+}
+
 #define TRY(x)                 \
     do {                       \
         int rc__ = (x);        \
@@ -313,11 +321,11 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
                       seed, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(int64_t, t->vq_idx),
                       WS(float, t->vq_rz), WS(void, t->vq_rzpad), 64, WS(float, t->vq_losses), WS(void, t->vq_ws), s));
     hipStream_t hs = (hipStream_t)s;
-    (void)hipMemcpyAsync(out->indices, WS(void, t->vq_idx), (size_t)t->Mq * 8, hipMemcpyDeviceToDevice, hs);
-    (void)hipMemcpyAsync(out->losses, WS(void, t->vq_losses), 16, hipMemcpyDeviceToDevice, hs);
-    if (out->unregularized_z) (void)hipMemcpyAsync(out->unregularized_z, WS(void, t->vq_zn), (size_t)t->Mq * c.d * 4, hipMemcpyDeviceToDevice, hs);
-    if (out->regularized_z) (void)hipMemcpyAsync(out->regularized_z, WS(void, t->vq_rz), (size_t)t->Mq * c.d * 4, hipMemcpyDeviceToDevice, hs);
-    if (out->emb) (void)hipMemcpyAsync(out->emb, WS(void, t->vq_E), (size_t)c.K * c.d * 4, hipMemcpyDeviceToDevice, hs);
+    TRY(copy_d2d(out->indices, WS(void, t->vq_idx), (size_t)t->Mq * 8, hs));
+    TRY(copy_d2d(out->losses, WS(void, t->vq_losses), 16, hs));
+    if (out->unregularized_z) TRY(copy_d2d(out->unregularized_z, WS(void, t->vq_zn), (size_t)t->Mq * c.d * 4, hs));
+    if (out->regularized_z) TRY(copy_d2d(out->regularized_z, WS(void, t->vq_rz), (size_t)t->Mq * c.d * 4, hs));
+    if (out->emb) TRY(copy_d2d(out->emb, WS(void, t->vq_E), (size_t)c.K * c.d * 4, hs));
     g = nt(WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, D, 64, VT_EPI_F32, out->encoded, D);
     g.bias = P->out_b; g.round_bf16 = 1;
     TRY(vt_gemm_nt(&g, s));
@@ -508,7 +516,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
                                G->codebook, WS(void, t->vq_ws), s));
             // in_linear: bias grad, wgrad, dgrad scattered into the last Nq rows of the encoder output gradient
             TRY(vt_colsum(WS(void, t->dz_pad), 1, 64, id, t->Mq, 64, WS(float, t->tmp_vec), WS(void, t->cs_ws), s));
-            (void)hipMemcpyAsync(G->in_b, WS(void, t->tmp_vec), (size_t)c.d * 4, hipMemcpyDeviceToDevice, hs);
+            TRY(copy_d2d(G->in_b, WS(void, t->tmp_vec), (size_t)c.d * 4, hs));
             w = tn(WS(void, t->dz_pad), 64, WS(void, t->zb), D, t->Mqp, 64, D, G->in_w, D);
             w.p_lim = c.d;
             TRY(skinny_wgrad(t, w, ws, s));
@@ -593,11 +601,11 @@ extern "C" int vt_stack_forward(vtStack* t, const vtBlockTensors* blocks, const 
     const int depth = t->c.depth_enc;
     const size_t bytes = (size_t)t->M * t->c.D * 4;
     hipStream_t hs = (hipStream_t)s;
-    (void)hipMemcpyAsync(WS(void, t->x_enc[0]), x_in, bytes, hipMemcpyDeviceToDevice, hs);
+    TRY(copy_d2d(WS(void, t->x_enc[0]), x_in, bytes, hs));
     TRY(pack_blocks(t, t->enc, blocks, ws, s));
     for (int i = 0; i < depth; ++i)
         TRY(block_forward(t, t->enc[i], blocks[i], WS(float, t->x_enc[i]), WS(float, t->x_enc[i + 1]), ws, s));
-    (void)hipMemcpyAsync(x_out, WS(void, t->x_enc[depth]), bytes, hipMemcpyDeviceToDevice, hs);
+    TRY(copy_d2d(x_out, WS(void, t->x_enc[depth]), bytes, hs));
     VT_CHECK_LAUNCH("vt_stack_forward");
     return VT_OK;
 }
@@ -612,7 +620,7 @@ extern "C" int vt_stack_backward(vtStack* t, const vtBlockTensors* blocks, const
     float* dX = WS(float, t->dX);
     t->pending.clear();
     t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
-    (void)hipMemcpyAsync(dX, dy, bytes, hipMemcpyDeviceToDevice, hs);
+    TRY(copy_d2d(dX, dy, bytes, hs));
     TRY(vt_cast_rows(dX, id, t->M, D, WS(void, t->gs[0].dx_out), D, s));
     TRY(vt_colsum(dX, 0, D, id, t->M, D, grads[depth - 1].fc2_b, WS(void, t->cs_ws), s));
     for (int i = depth - 1; i >= 0; --i) {
@@ -624,7 +632,7 @@ extern "C" int vt_stack_backward(vtStack* t, const vtBlockTensors* blocks, const
             TRY(flush_wgrads(t, 0, s));
         }
     }
-    (void)hipMemcpyAsync(dx, dX, bytes, hipMemcpyDeviceToDevice, hs);
+    TRY(copy_d2d(dx, dX, bytes, hs));
     VT_CHECK_LAUNCH("vt_stack_backward");
     return VT_OK;
 }
