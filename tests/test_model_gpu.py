@@ -365,3 +365,39 @@ def test_rfvd_evaluator_loop_with_injected_detector():
         short = [{"gt": c[:, :, : T // 2]} for c in clips[:1]]
         m2, p2, f2, _ = UCFrFVDEvaluator(model, loader=short, detector=detector, frame_num=T // 2, crop_size=S).evaluate(no_fvd=True)
         assert np.isfinite(m2) and f2 == -1.0
+
+
+def test_bad_inputs_raise_python_errors_not_faults():
+    """wrong geometry, wrong channel count, non-finite pixels, fp16/bf16/fp64 inputs: the reference's asserts (embed.py:87-104)
+    or a clean HipError -- never a kernel launch on mismatched shapes"""
+    import video_tokenizer_amd as vt
+    cfg = O.make_cfg("tiny")
+    model, _ = build(cfg)
+    T, S = cfg["frame_num"], cfg["input_size"]
+    good = torch.from_numpy(gen.video_clips(1, T, S, 5)).cuda()
+    with pytest.raises(AssertionError):
+        model(good[:, :, :, : S // 2])                      # height mismatch under strict_vid_size
+    with pytest.raises(AssertionError):
+        model(good[:, :2])                                  # two channels
+    with pytest.raises(AssertionError):
+        model(good[0])                                      # not 5-D
+    with pytest.raises(AssertionError):
+        model(torch.cat([good, good], dim=2))               # twice the frames
+    model.x_embedder.strict_vid_size = False
+    with pytest.raises(AssertionError):
+        model(good[:, :, : T - 1])                          # frame count not divisible by the temporal patch
+    model.x_embedder.strict_vid_size = True
+    with pytest.raises(vt.hip.HipError):
+        model.decode(torch.zeros(1, cfg["bottleneck_token_num"], 768))      # CPU tensor
+    # other floating dtypes are accepted and converted like the reference's .float() paths
+    a = model(good)["pred_frames"]
+    for dt in (torch.float64, torch.bfloat16):
+        b = model(good.to(dt))["pred_frames"]
+        assert b.dtype == torch.float32 and b.shape == a.shape
+    assert torch.equal(model(good.double())["pred_frames"], a)
+    # non-finite pixels propagate as NaN, they do not hang or fault
+    bad = good.clone()
+    bad[0, 0, 0, 0, 0] = float("nan")
+    out = model(bad)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out["pred_frames"]).all()
