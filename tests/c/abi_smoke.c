@@ -5,6 +5,17 @@
 
 #include "vt_hip.h"
 
+/* The call sequence of INTEGRATION.md section 3, compile-checked against the header (never executed here: it needs a GPU). */
+static int example_training_step(vtTokenizer* tk, const vtTokenizerTensors* params, const vtTokenizerTensors* grads, const float* video,
+                                 void* ws, const vtTokenizerOutputs* out, const float* d_pred, const float* gscal, vtStream stream) {
+    int rc = vt_tokenizer_init_workspace(tk, ws, stream);
+    if (!rc) rc = vt_tokenizer_pack(tk, params, ws, stream);
+    if (!rc) rc = vt_tokenizer_encode(tk, params, video, ws, out, 1234u, stream);
+    if (!rc) rc = vt_tokenizer_decode(tk, params, out->encoded, ws, out->pred_frames, stream);
+    if (!rc) rc = vt_tokenizer_backward(tk, params, d_pred, gscal, ws, grads, 0, vt_tokenizer_num_backward_stages(tk), NULL, stream);
+    return rc;
+}
+
 int main(void) {
     char msg[256];
     vtGemmNT g;
@@ -14,6 +25,7 @@ int main(void) {
     vtStack* st = NULL;
     int rc;
 
+    (void)example_training_step;
     printf("abi %d\n", vt_abi_version());
     memset(&g, 0, sizeof g);
     rc = vt_gemm_nt(&g, NULL);                      /* null operands: rejected before any launch */
