@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--gan", action="store_true",
                     help="also time the step with the GAN branch of the trainer (discriminator of cfgs/larp_tokenizer.yaml:113-136, LPIPS off): "
                          "reported under the extra key 'gan_step'; the headline metric is unchanged")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal of the N > 1 code path on one GPU: process group, DataParallelTokenizer, barriers and the MAX all-reduce at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -178,9 +180,11 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
 
     import video_tokenizer_amd as vt
     from video_tokenizer_amd.parallel import DataParallelTokenizer
@@ -192,7 +196,7 @@ def main():
     with torch.no_grad():  # the reference zero-inits the head (larp_tokenizer.py:327-328) => all-zero output and dead gradients
         torch.nn.init.xavier_uniform_(model.final_layer.linear.weight)
     model = model.to(dev).train()
-    net = DataParallelTokenizer(model) if world > 1 else model
+    net = DataParallelTokenizer(model) if multi else model
     if a.optimizer == "torch":
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.5, 0.9))
     elif a.optimizer == "fused":
@@ -220,7 +224,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -230,11 +234,11 @@ def main():
         loss = step()
         host.append(time.perf_counter() - h0)  # host-side enqueue time of the step (no sync inside)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -276,7 +280,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": None, "kind": "port", "sample": None, "error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()  # rank 0 may still be replaying the dominant kernel for `roofline`: nobody tears the group down early
         dist.destroy_process_group()
 

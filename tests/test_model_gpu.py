@@ -401,3 +401,26 @@ def test_bad_inputs_raise_python_errors_not_faults():
     out = model(bad)
     torch.cuda.synchronize()
     assert not torch.isfinite(out["pred_frames"]).all()
+
+
+def test_bench_contract_and_distributed_rehearsal():
+    """bench.py prints ONE JSON line with the contract's keys; --force-dist drives the N > 1 code path (RCCL process group,
+    bucketed all-reduce on the side stream, barriers, MAX over ranks, teardown) at world size 1 on this GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["unit"] == "clips/s" and r["scaling"] == "weak" and r["dtype"] == "bf16"
+    assert r["value"] > 50 and "workload" in r["config"] and r["vs_baseline"] is None
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and 0.05 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
