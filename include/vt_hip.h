@@ -173,6 +173,15 @@ int vt_unpatchify(const float* rows, int32_t B, int32_t C, int32_t T, int32_t S,
 int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream);
 int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
                      int32_t hd, void* dqkv, float* delta_ws, vtStream stream);
+/* The same for the queries q_begin .. L-1 only (q_begin a multiple of 64): `transformer_encoder_parallel` returns
+ * h[:, -len(query):] (models/transformer.py:69), so in the LAST block of a stack the other rows' attention outputs are
+ * never read and their output gradients are zero.  o / dO are compact [B, L - q_begin, H, hd]; keys/values, lse2,
+ * delta_ws and dqkv keep the full length (dQ rows before q_begin are written as zeros, dK/dV get the kept queries'
+ * contributions). */
+int vt_attention_fwd_rows(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t q_begin, void* o_compact, float* lse2,
+                          vtStream stream);
+int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
+                          int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vector quantisation (SimpleVectorQuantizer.forward, models/bottleneck.py:262-324).

@@ -267,6 +267,31 @@ def test_attention_fwd_bwd(hip, B, L, H, hd):
     assert err < 3e-2, err
 
 
+@pytest.mark.parametrize("B,L,H,hd,q_begin", [(2, 192, 2, 64, 64), (1, 320, 3, 64, 128), (2, 200, 2, 32, 64), (1, 1536, 1, 64, 1024)])
+def test_attention_kept_query_suffix(hip, B, L, H, hd, q_begin):
+    """vt_attention_*_rows: queries q_begin..L-1 only (last block of a stack), compact o / dO, full-length keys and dqkv"""
+    qkv = bf(_rand((B * L, 3 * H * hd), 150 + L))
+    Lq = L - q_begin
+    dOc = bf(_rand((B * Lq, H * hd), 151 + L))
+    x = qkv.float().requires_grad_(True)
+    full = _attn_ref(x, B, L, H, hd).reshape(B, L, H * hd)[:, q_begin:].reshape(B * Lq, H * hd)
+    full.backward(dOc.float())
+    o, lse2 = hip.attention_fwd(qkv.cuda(), B, L, H, hd, q_begin=q_begin)
+    torch.cuda.synchronize()
+    assert o.shape == (B * Lq, H * hd)
+    np.testing.assert_allclose(o.float().cpu().numpy(), full.detach().numpy(), rtol=2e-2, atol=2e-2)
+    # same kernels as the full call: the kept rows are bit-equal to it
+    o_all, lse_all = hip.attention_fwd(qkv.cuda(), B, L, H, hd)
+    assert torch.equal(o, o_all.reshape(B, L, H * hd)[:, q_begin:].reshape(B * Lq, H * hd))
+    assert torch.equal(lse2[:, :, q_begin:], lse_all[:, :, q_begin:])
+    dqkv = hip.attention_bwd(qkv.cuda(), o, dOc.cuda(), lse2, B, L, H, hd, q_begin=q_begin)
+    torch.cuda.synchronize()
+    g = x.grad
+    assert (dqkv.float().cpu() - g).abs().max() / g.abs().max() < 3e-2
+    dq_rows = dqkv.reshape(B, L, 3, H * hd)[:, :q_begin, 0]
+    assert torch.all(dq_rows == 0)                                   # queries before q_begin: exactly zero gradient
+
+
 @pytest.mark.parametrize("hd", [64, 32])
 def test_attention_integer_identity(hip, hd):
     """One-hot V columns + peaked scores: checks the transposed-read PV product element by element."""

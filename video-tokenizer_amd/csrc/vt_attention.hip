@@ -199,7 +199,7 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
 // ------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
-                                                           int L, int H, int nblk, float scale_log2e) {
+                                                           int L, int H, int nblk, float scale_log2e, int q_begin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
     const bf16_t* vb = kb + (int64_t)H * HD;
-    const int q0 = blk * 128 + wave * 32;
+    // queries q_begin .. L-1 only (q_begin > 0: the last block of a stack, whose other output rows nobody reads); their
+    // outputs go to a COMPACT o [B, L - q_begin, H, HD]; keys are always all L rows; lse2 keeps the full [B, H, L] index
+    const int q0 = q_begin + blk * 128 + wave * 32;
+    const int Lq = L - q_begin;
 
     constexpr int TILE = AG<HD>::TILE, KS = AG<HD>::KS, DT = AG<HD>::DT;
     bf16x8 qf[KS];
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const int q = q0 + (lane & 31);
     const bool ok = q < L;
-    store_own<DT>(oacc, 1.0f / ltot, o + (int64_t)b * L * H * HD + (int64_t)h * HD, (int64_t)H * HD, q, ok, half);
+    store_own<DT>(oacc, 1.0f / ltot, o + (int64_t)b * Lq * H * HD + (int64_t)h * HD, (int64_t)H * HD, q - q_begin, ok, half);
     if (ok && half == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);  // v_log_f32 = log2
 }
 
@@ -303,7 +306,7 @@ template <int HD>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ dO, const float* __restrict__ lse2,
                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, int H, int nblk,
-                                                              float scale, float scale_log2e) {
+                                                              float scale, float scale_log2e, int q_begin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -315,19 +318,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
     const bf16_t* vb = kb + (int64_t)H * HD;
-    const int q0 = blk * 128 + wave * 32;
+    const int q0 = q_begin + blk * 128 + wave * 32;   // kept queries only; o / dO are compact [B, L - q_begin, H, HD]
+    const int Lq = L - q_begin;
     const int q = q0 + (lane & 31);
     const int qc = q < L ? q : L - 1;
 
     constexpr int TILE = AG<HD>::TILE, KS = AG<HD>::KS, DT = AG<HD>::DT;
     bf16x8 qf[KS], dof[KS];
     load_own<KS>(qb, rs, q0, L, lane, qf);
-    load_own<KS>(dO + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, dof);
+    load_own<KS>(dO + (int64_t)b * Lq * ors + (int64_t)h * HD, ors, q0 - q_begin, Lq, lane, dof);
     const float my_lse = lse2[((int64_t)b * H + h) * L + qc];
     float my_delta = 0.f;
     {
         bf16x8 of[KS];
-        load_own<KS>(o + (int64_t)b * L * ors + (int64_t)h * HD, ors, q0, L, lane, of);
+        load_own<KS>(o + (int64_t)b * Lq * ors + (int64_t)h * HD, ors, q0 - q_begin, Lq, lane, of);
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -426,7 +430,8 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e) {
+                                                               bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e,
+                                                               int q_begin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -438,7 +443,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
     const bf16_t* vb = kb + (int64_t)H * HD;
-    const bf16_t* dob = dO + (int64_t)b * L * ors + (int64_t)h * HD;
+    // query tiles from q_begin on (a multiple of 64; the rows before it got no gradient), dO compact [B, L - q_begin, H, HD]
+    const int Lq = L - q_begin;
+    const bf16_t* dob = dO + (int64_t)b * Lq * ors + (int64_t)h * HD;
     const float* lse_b = lse2 + ((int64_t)b * H + h) * L;
     const float* del_b = delta + ((int64_t)b * H + h) * L;
     const int k0 = blk * 128 + wave * 32;
@@ -467,10 +474,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const unsigned base = sbase + buf * BUF;
         if (t < nfull_q) {
             stage64_full<HD>(qb + (int64_t)t * 64 * rs, qoff, base, wave);
-            stage64_full<HD>(dob + (int64_t)t * 64 * ors, dooff, base + TILE, wave);
+            stage64_full<HD>(dob + ((int64_t)t * 64 - q_begin) * ors, dooff, base + TILE, wave);
         } else {
             stage64<HD>(qb, rs, t * 64, L, base, tid, wave);
-            stage64<HD>(dob, ors, t * 64, L, base + TILE, tid, wave);
+            stage64<HD>(dob, ors, t * 64 - q_begin, Lq, base + TILE, tid, wave);
         }
         if (wave < 2) {  // wave 0: lse2[64], wave 1: delta[64] by 4-byte LDS-DMA (rows past L clamped; masked at use)
             int qq = t * 64 + lane;
@@ -478,59 +485,96 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             glds4_asm((wave == 0 ? lse_b : del_b) + qq, base + 2 * TILE + wave * 256);
         }
     };
-    stage(0, 0);
+    const int t0 = q_begin >> 6;
+    stage(t0, 0);
     dma_drain();
     __syncthreads();
 
     const int nfull = (L & 63) ? nt - 1 : nt;
-    for (int t = 0; t < nfull; ++t) {
-        const int cur = t & 1;
+    for (int t = t0; t < nfull; ++t) {
+        const int cur = (t - t0) & 1;
         if (t + 1 < nt) stage(t + 1, cur ^ 1);
         dkv_tile<HD, false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
         dma_drain();
         __syncthreads();
     }
-    if (nfull < nt) dkv_tile<HD, true>(smem + (nfull & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
+    if (nfull < nt) dkv_tile<HD, true>(smem + ((nfull - t0) & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
     bf16_t* dkb = dqkv + (int64_t)b * L * rs + (int64_t)h * HD + (int64_t)H * HD;
     store_own<DT>(dk, scale, dkb, rs, key, key < L, half);
     store_own<DT>(dv, 1.0f, dkb + (int64_t)H * HD, rs, key, key < L, half);
 }
 
+// dQ rows of the queries before q_begin: they received no gradient (the dQ kernel only visits the kept queries)
+__global__ void zero_q_rows_kernel(bf16_t* __restrict__ dqkv, int L, int q_begin, int64_t rs, int qcols) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * q_begin * qcols / 8
+    const int per_row = qcols >> 3;
+    const int64_t r = idx / per_row;
+    const int c = (int)(idx % per_row) * 8;
+    const int64_t b = r / q_begin, q = r % q_begin;
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = f2bf(0.f);
+    *(bf16x8*)(dqkv + (b * L + q) * rs + c) = z;
+}
+
 }  // namespace
 
 template <int HD>
-static void launch_fwd(const void* qkv, int B, int L, int H, void* o, float* lse2, hipStream_t s) {
+static void launch_fwd(const void* qkv, int B, int L, int H, int q_begin, void* o, float* lse2, hipStream_t s) {
     const float sl2 = (HD == 64 ? 0.125f : 0.17677669529663688110f) * 1.44269504088896340736f;
-    const int nblk = (L + 127) / 128;
-    hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2);
+    const int nblk = (L - q_begin + 127) / 128;
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2, q_begin);
 }
 
 template <int HD>
-static void launch_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int L, int H, void* dqkv, float* delta_ws, hipStream_t s) {
+static void launch_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int L, int H, int q_begin, void* dqkv,
+                       float* delta_ws, hipStream_t s) {
     const float scale = HD == 64 ? 0.125f : 0.17677669529663688110f, sl2 = scale * 1.44269504088896340736f;
-    const int nblk = (L + 127) / 128;
-    const dim3 grid(nblk * B * H);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, grid, dim3(256), 2 * (2 * AG<HD>::TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2);
+    if (q_begin > 0) {
+        const int64_t n = (int64_t)B * q_begin * (H * HD / 8);
+        hipLaunchKernelGGL(zero_q_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)dqkv, L, q_begin, (int64_t)3 * H * HD, H * HD);
+    }
+    const int nblk_q = (L - q_begin + 127) / 128, nblk_k = (L + 127) / 128;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3(nblk_q * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO, lse2,
+                       delta_ws, (bf16_t*)dqkv, L, H, nblk_q, scale, sl2, q_begin);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3(nblk_k * B * H), dim3(256), 2 * (2 * AG<HD>::TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2,
+                       delta_ws, (bf16_t*)dqkv, L, H, nblk_k, scale, sl2, q_begin);
 }
 
-extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream) {
-    VT_CHECK_ARG(qkv && o && lse2, "vt_attention_fwd: null pointer");
-    VT_CHECK_ARG(hd == 64 || hd == 32, "vt_attention_fwd: head_dim %d unsupported (64 or 32)", hd);
-    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_fwd: bad shape");
-    if (hd == 64) launch_fwd<64>(qkv, B, L, H, o, lse2, (hipStream_t)stream);
-    else launch_fwd<32>(qkv, B, L, H, o, lse2, (hipStream_t)stream);
+static int attn_check(const char* who, int B, int L, int H, int hd, int q_begin) {
+    VT_CHECK_ARG(hd == 64 || hd == 32, "%s: head_dim %d unsupported (64 or 32)", who, hd);
+    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "%s: bad shape", who);
+    VT_CHECK_ARG(q_begin >= 0 && q_begin < L && q_begin % 64 == 0, "%s: q_begin=%d must be a multiple of 64 below L=%d", who, q_begin, L);
+    return VT_OK;
+}
+
+extern "C" int vt_attention_fwd_rows(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t q_begin, void* o_compact, float* lse2,
+                                     vtStream stream) {
+    VT_CHECK_ARG(qkv && o_compact && lse2, "vt_attention_fwd: null pointer");
+    int rc = attn_check("vt_attention_fwd", B, L, H, hd, q_begin);
+    if (rc) return rc;
+    if (hd == 64) launch_fwd<64>(qkv, B, L, H, q_begin, o_compact, lse2, (hipStream_t)stream);
+    else launch_fwd<32>(qkv, B, L, H, q_begin, o_compact, lse2, (hipStream_t)stream);
     VT_CHECK_LAUNCH("vt_attention_fwd");
     return VT_OK;
 }
 
-extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
-                                int32_t hd, void* dqkv, float* delta_ws, vtStream stream) {
-    VT_CHECK_ARG(qkv && o && dO && lse2 && dqkv && delta_ws, "vt_attention_bwd: null pointer");
-    VT_CHECK_ARG(hd == 64 || hd == 32, "vt_attention_bwd: head_dim %d unsupported (64 or 32)", hd);
-    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_bwd: bad shape");
-    if (hd == 64) launch_bwd<64>(qkv, o, dO, lse2, B, L, H, dqkv, delta_ws, (hipStream_t)stream);
-    else launch_bwd<32>(qkv, o, dO, lse2, B, L, H, dqkv, delta_ws, (hipStream_t)stream);
+extern "C" int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
+                                     int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, vtStream stream) {
+    VT_CHECK_ARG(qkv && o_compact && dO_compact && lse2 && dqkv && delta_ws, "vt_attention_bwd: null pointer");
+    int rc = attn_check("vt_attention_bwd", B, L, H, hd, q_begin);
+    if (rc) return rc;
+    if (hd == 64) launch_bwd<64>(qkv, o_compact, dO_compact, lse2, B, L, H, q_begin, dqkv, delta_ws, (hipStream_t)stream);
+    else launch_bwd<32>(qkv, o_compact, dO_compact, lse2, B, L, H, q_begin, dqkv, delta_ws, (hipStream_t)stream);
     VT_CHECK_LAUNCH("vt_attention_bwd");
     return VT_OK;
+}
+
+extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream) {
+    return vt_attention_fwd_rows(qkv, B, L, H, hd, 0, o, lse2, stream);
+}
+
+extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
+                                int32_t hd, void* dqkv, float* delta_ws, vtStream stream) {
+    return vt_attention_bwd_rows(qkv, o, dO, lse2, B, L, H, hd, 0, dqkv, delta_ws, stream);
 }

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vt_unpatchify": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vt_attention_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_attention_fwd_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_attention_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -305,17 +307,18 @@ def unpatchify(rows, B, C, T, S, pt, p):
     return video
 
 
-def attention_fwd(qkv, B, L, H, hd=64, o=None):
-    o = torch.empty(B * L, H * hd, device=qkv.device, dtype=torch.bfloat16) if o is None else o
-    lse2 = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
-    check(lib().vt_attention_fwd(ptr(qkv), B, L, H, hd, ptr(o), ptr(lse2), stream()), "vt_attention_fwd")
+def attention_fwd(qkv, B, L, H, hd=64, o=None, q_begin=0):
+    """q_begin > 0: only the queries q_begin..L-1; o is then compact [B * (L - q_begin), H * hd]"""
+    o = torch.empty(B * (L - q_begin), H * hd, device=qkv.device, dtype=torch.bfloat16) if o is None else o
+    lse2 = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32) if q_begin else torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
+    check(lib().vt_attention_fwd_rows(ptr(qkv), B, L, H, hd, q_begin, ptr(o), ptr(lse2), stream()), "vt_attention_fwd")
     return o, lse2
 
 
-def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None):
+def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0):
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
-    delta = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
-    check(lib().vt_attention_bwd(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
+    delta = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32)
+    check(lib().vt_attention_bwd_rows(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
     return dqkv
 
 
