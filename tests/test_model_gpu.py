@@ -38,11 +38,13 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("name,B", [("tiny", 2), ("tiny_ragged", 1)])
+@pytest.mark.parametrize("name,B", [("tiny", 2), ("tiny_ragged", 1), ("tiny_lastskip", 2)])
 def test_forward_backward_matches_oracle(name, B):
     over = {}
     if name == "tiny_ragged":  # L = 8 + 37 = 45: exercises every tail path (M, L not multiples of any tile)
         name, over = "tiny", {"bottleneck_token_num": 37}
+    if name == "tiny_lastskip":  # Nv = 64, Nq = 128: both stacks' last blocks take the kept-rows-only path (first kept row % 64 == 0)
+        name, over = "tiny", {"frame_num": 8, "input_size": 64, "bottleneck_token_num": 128}
     cfg = O.make_cfg(name, **over)
     model, sd = build(cfg)
     x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 11))

@@ -87,6 +87,12 @@ struct vtTokenizer {
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
     // is the next block's dx_out set).
+    // The LAST block of a stack only has to produce the rows the stack returns (transformer.py:69: h[:, -len(query):]): the
+    // last nk rows of every sequence.  Its MLP half, the attention queries and the matching backward work run on those rows
+    // only (compact buffers); K/V, the qkv GEMM and LayerNorm1 still cover all rows.  Enabled per stack when the first kept
+    // row (L - nk) is a multiple of 64.
+    struct LastBlock { int enabled, nk, q_begin, Mk, Mkp; size_t dxa, dxm, du; };
+    LastBlock last_enc, last_dec;
     struct GradSet { size_t dx_out, dx_mid, du, dqkv; };
     static constexpr int WG_BATCH = 4;
     GradSet gs[WG_BATCH + 1];
@@ -175,6 +181,15 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
         g.du = a.take(Mp * t->D4 * 2); g.dqkv = a.take(Mp * t->D3 * 2);
     }
     t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
+    for (int which = 0; which < 2; ++which) {
+        vtTokenizer::LastBlock& lb = which == 0 ? t->last_enc : t->last_dec;
+        lb.nk = which == 0 ? c.Nq : t->Nv;
+        lb.q_begin = t->L - lb.nk;
+        lb.Mk = c.B * lb.nk;
+        lb.Mkp = round_up(lb.Mk, 128);
+        lb.enabled = (lb.q_begin % 64 == 0 && lb.q_begin > 0) ? 1 : 0;
+        lb.dxa = a.take((size_t)lb.Mkp * D * 2); lb.dxm = a.take((size_t)lb.Mkp * D * 2); lb.du = a.take((size_t)lb.Mkp * t->D4 * 2);
+    }
     t->delta = a.take((size_t)c.B * c.H * t->L * 4);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
@@ -288,6 +303,30 @@ static int block_forward(vtTokenizer* t, const BlockBufs& b, const vtBlockTensor
     return VT_OK;
 }
 
+// The last block of a stack (see vtTokenizer::LastBlock): rows outside the kept suffix of x_out are NOT written.
+static int block_forward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb, const BlockBufs& b, const vtBlockTensors& w, const float* x_in,
+                              float* x_out, void* ws, vtStream s) {
+    const vtTokenizerConfig& c = t->c;
+    const int M = t->M, D = c.D, D3 = t->D3, D4 = t->D4, Mk = lb.Mk;
+    const vtRowMap id = {0, 0, 0};
+    const vtRowMap kmap = {lb.nk, t->L, lb.q_begin};
+    TRY(vt_layernorm_fwd(x_in, id, w.norm1_w, w.norm1_b, 1e-5f, M, D, WS(void, b.h1), WS(float, b.mean1), WS(float, b.rstd1), s));
+    vtGemmNT g = nt(WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_attention_fwd_rows(WS(void, b.qkv), c.B, t->L, c.H, c.D / c.H, lb.q_begin, WS(void, b.o), WS(float, b.lse), s));
+    g = nt(WS(void, b.o), D, WS(void, b.proj_wb), D, Mk, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
+    g.bias = w.proj_b; g.residual = x_in; g.ldr = D; g.omap = kmap;
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_layernorm_fwd(WS(float, b.x_mid), kmap, w.norm2_w, w.norm2_b, 1e-5f, Mk, D, WS(void, b.h2), WS(float, b.mean2), WS(float, b.rstd2), s));
+    g = nt(WS(void, b.h2), D, WS(void, b.fc1_wb), D, Mk, D4, D, VT_EPI_BF16_GELU, WS(void, b.u), D4);
+    g.out2 = WS(void, b.g); g.ldo2 = D4; g.bias = w.fc1_b;
+    TRY(vt_gemm_nt(&g, s));
+    g = nt(WS(void, b.g), D4, WS(void, b.fc2_wb), D4, Mk, D, D4, VT_EPI_F32, x_out, D);
+    g.bias = w.fc2_b; g.residual = WS(float, b.x_mid); g.ldr = D; g.omap = kmap;
+    TRY(vt_gemm_nt(&g, s));
+    return VT_OK;
+}
+
 extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, const float* video, void* ws,
                                    const vtTokenizerOutputs* out, uint64_t seed, vtStream s) {
     VT_CHECK_ARG(t && P && video && ws && out, "vt_tokenizer_encode: null pointer");
@@ -304,8 +343,12 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
     // 2. learned latent queries broadcast into rows [Nv, L)   (larp_tokenizer.py:410, transformer.py:64)
     TRY(vt_assemble_rows(x0, L, Nv, c.B, Nq, D, nullptr, P->enc_query, nullptr, s));
     // 3. encoder blocks
-    for (int i = 0; i < c.depth_enc; ++i)
-        TRY(block_forward(t, t->enc[i], P->enc_blocks[i], WS(float, t->x_enc[i]), WS(float, t->x_enc[i + 1]), ws, s));
+    for (int i = 0; i < c.depth_enc; ++i) {
+        if (i == c.depth_enc - 1 && t->last_enc.enabled)
+            TRY(block_forward_last(t, t->last_enc, t->enc[i], P->enc_blocks[i], WS(float, t->x_enc[i]), WS(float, t->x_enc[i + 1]), ws, s));
+        else
+            TRY(block_forward(t, t->enc[i], P->enc_blocks[i], WS(float, t->x_enc[i]), WS(float, t->x_enc[i + 1]), ws, s));
+    }
     const float* xe = WS(float, t->x_enc[c.depth_enc]);
     const vtRowMap qmap = {Nq, L, Nv};  // the last Nq rows of every sequence (transformer.py:69)
     // 4. bottleneck: norm stats, in_linear, VQ, out_linear
@@ -353,8 +396,12 @@ extern "C" int vt_tokenizer_decode(vtTokenizer* t, const vtTokenizerTensors* P, 
     // decoder sequence = [encoded + latent PE | patch queries (+ token type)]   (larp_tokenizer.py:463-466)
     TRY(vt_assemble_rows(x0, L, 0, c.B, Nq, D, encoded, P->dec_latent_pe, nullptr, s));
     TRY(vt_assemble_rows(x0, L, Nq, c.B, Nv, D, nullptr, WS(float, t->dec_query_sum), nullptr, s));
-    for (int i = 0; i < c.depth_dec; ++i)
-        TRY(block_forward(t, t->dec[i], P->dec_blocks[i], WS(float, t->x_dec[i]), WS(float, t->x_dec[i + 1]), ws, s));
+    for (int i = 0; i < c.depth_dec; ++i) {
+        if (i == c.depth_dec - 1 && t->last_dec.enabled)
+            TRY(block_forward_last(t, t->last_dec, t->dec[i], P->dec_blocks[i], WS(float, t->x_dec[i]), WS(float, t->x_dec[i + 1]), ws, s));
+        else
+            TRY(block_forward(t, t->dec[i], P->dec_blocks[i], WS(float, t->x_dec[i]), WS(float, t->x_dec[i + 1]), ws, s));
+    }
     // head on the last Nv rows: LayerNorm(1e-6) -> Linear (rows permuted to (c,dt,dy,dx)) -> unpatchify
     const vtRowMap vmap = {Nv, L, Nq};
     TRY(vt_layernorm_fwd(WS(float, t->x_dec[c.depth_dec]), vmap, P->head_norm_w, P->head_norm_b, 1e-6f, t->Mv, D, WS(void, t->hN),
@@ -457,6 +504,49 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     return VT_OK;
 }
 
+// Backward of the last block of a stack: dL/dx_out is zero outside the kept rows, so the MLP half, proj and the query side of
+// attention run on the compact kept rows; qkv input gradient, K/V gradients and LayerNorm1 cover all rows as usual.
+static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb, const BlockBufs& b, const vtBlockTensors& w,
+                               const vtBlockTensors& gr, const float* x_in, float* prev_bias_grad, void* ws, vtStream s) {
+    const vtTokenizerConfig& c = t->c;
+    const int M = t->M, Mp = t->Mp, D = c.D, D3 = t->D3, D4 = t->D4, Mk = lb.Mk, Mkp = lb.Mkp;
+    const vtRowMap id = {0, 0, 0};
+    const vtRowMap kmap = {lb.nk, t->L, lb.q_begin};
+    const vtTokenizer::GradSet& g0 = t->gs[t->set_idx];
+    const vtTokenizer::GradSet& g1 = t->gs[(t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1)];
+    float* dX = WS(float, t->dX);
+    void* dXa = WS(void, lb.dxa);   // compact bf16 copies of dL/dx_out and dL/dx_mid, and du: rows >= Mk stay zero
+    void* dXm = WS(void, lb.dxm);
+    void* du = WS(void, lb.du);
+    void* dqkv = WS(void, g0.dqkv);
+    TRY(vt_cast_rows(dX, kmap, Mk, D, dXa, D, s));
+    vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, Mk, D4, D, VT_EPI_BF16_DGELU, du, D4);
+    g.aux = WS(void, b.u); g.ldaux = D4;
+    g.colsum_partial = WS(float, t->cs_part);
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_sum_slabs(WS(float, t->cs_part), (Mk + 191) / 192, D4, D4, gr.fc1_b, s));
+    g = nt(du, D4, WS(void, b.fc1_wt), D4, Mk, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_layernorm_bwd(WS(void, t->dh), WS(float, b.x_mid), kmap, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, Mk, D, dX, nullptr,
+                         gr.norm2_w, gr.norm2_b, gr.proj_b, WS(void, t->ln_ws), s));
+    TRY(vt_cast_rows(dX, kmap, Mk, D, dXm, D, s));
+    g = nt(dXm, D, WS(void, b.proj_wt), D, Mk, D, D, VT_EPI_BF16, WS(void, t->dob), D);
+    TRY(vt_gemm_nt(&g, s));
+    TRY(vt_attention_bwd_rows(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, c.D / c.H, lb.q_begin, dqkv,
+                              WS(float, t->delta), s));
+    g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
+    TRY(vt_gemm_nt(&g, s));
+    t->pending.push_back(tn(dXa, D, WS(void, b.g), D4, Mkp, D, D4, gr.fc2_w, D4));
+    t->pending.push_back(tn(du, D4, WS(void, b.h2), D, Mkp, D4, D, gr.fc1_w, D));
+    t->pending.push_back(tn(dXm, D, WS(void, b.o), D, Mkp, D, D, gr.proj_w, D));
+    t->pending.push_back(tn(dqkv, D3, WS(void, b.h1), D, Mp, D3, D, gr.qkv_w, D));
+    t->pending_blocks++;
+    TRY(vt_layernorm_bwd(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
+                         gr.norm1_w, gr.norm1_b, prev_bias_grad, WS(void, t->ln_ws), s));
+    t->set_idx = (t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1);
+    return VT_OK;
+}
+
 extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P, const float* d_pred, const float* gscal, void* ws,
                                      const vtTokenizerTensors* G, int32_t stage_begin, int32_t stage_end, int32_t* final_through,
                                      vtStream s) {
@@ -497,7 +587,10 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
         } else if (st <= c.depth_dec) {
             const int i = c.depth_dec - st;  // decoder blocks, last first
             float* prev = i > 0 ? G->dec_blocks[i - 1].fc2_b : nullptr;
-            TRY(block_backward(t, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), prev, ws, s));
+            if (i == c.depth_dec - 1 && t->last_dec.enabled)
+                TRY(block_backward_last(t, t->last_dec, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), prev, ws, s));
+            else
+                TRY(block_backward(t, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), prev, ws, s));
             if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) TRY(flush_wgrads(t, st + 1, s));
         } else if (st == c.depth_dec + 1) {
             // ---- bottleneck.  dX holds dL/d(decoder input sequence)
@@ -530,7 +623,10 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
         } else if (st <= c.depth_dec + 1 + c.depth_enc) {
             const int i = c.depth_enc - (st - c.depth_dec - 1);
             float* prev = i > 0 ? G->enc_blocks[i - 1].fc2_b : nullptr;
-            TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
+            if (i == c.depth_enc - 1 && t->last_enc.enabled)
+                TRY(block_backward_last(t, t->last_enc, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
+            else
+                TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
             if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) TRY(flush_wgrads(t, st + 1, s));
         } else {
             // ---- patch embed + learned queries.  dX holds dL/d(encoder input sequence)
@@ -567,6 +663,8 @@ extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
     t->M = B * L; t->Mp = round_up(t->M, 128);
     t->Mv = t->Mvp = t->Mq = t->Mqp = t->Kp = 0;
     t->D3 = 3 * D; t->D4 = 4 * D;
+    memset(&t->last_enc, 0, sizeof(t->last_enc));
+    memset(&t->last_dec, 0, sizeof(t->last_dec));
     Arena a;
     const size_t Mp = t->Mp;
     plan_blocks(t, a, t->enc, depth);
