@@ -217,6 +217,23 @@ int vt_vq_gather(const float* E, const int64_t* idx, int32_t N, int32_t K, int32
 
 
 /* ------------------------------------------------------------------------------------------
+ * Finite scalar quantizer: FSQ.forward / quantize / codes_to_indices / indices_to_codes of the reference's
+ * TiTok-style autoencoders (models/model_new/quantizer/fsq.py:76-131; levels [8,8,8,5,5,5] or [8,8,8,8,5,5,5,5],
+ * models/model_new/autoencoder.py:59,140,640).  z, codes, dcodes, dz are [N, d] row-major, fp32 (is_bf16 = 0) or
+ * bf16 (is_bf16 = 1: the reference up-casts to fp32, computes, and casts codes back, :122-129); indices int32 [N]
+ * (may be NULL in forward).  `levels_host`: d ints on the HOST, each >= 2, prod <= 2^24, d <= 16.
+ * Backward is the straight-through estimator autograd derives: dz = dcodes / (levels // 2) * half_l * (1 - tanh^2).
+ * One launch each; indices and codes are bit-exact against the reference's fp32 arithmetic.
+ * ------------------------------------------------------------------------------------------ */
+int vt_fsq_codebook_size(const int32_t* levels_host, int32_t d, int64_t* size);
+int vt_fsq_forward(const void* z, int32_t is_bf16, int64_t N, int32_t d, const int32_t* levels_host, void* codes,
+                   int32_t* indices, vtStream stream);
+int vt_fsq_backward(const void* z, const void* dcodes, int32_t is_bf16, int64_t N, int32_t d, const int32_t* levels_host,
+                    void* dz, vtStream stream);
+int vt_fsq_indices_to_codes(const int32_t* indices, int64_t N, int32_t d, const int32_t* levels_host, void* codes,
+                            int32_t is_bf16, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused Adam (+ optional EMA) over flat fp32 buffers: replaces optimizer.step() of torch.optim.Adam
  * (trainers/larp_tokenizer_trainer.py:160-212 builds Adam(lr, betas); :376-377 steps it) and
  * update_ema (trainers/base_trainer.py:769-779), one HBM-bound pass.  n % 4 == 0; step counts from 1;

@@ -176,10 +176,38 @@ def make_embed(emb, out):
     print("sincos fixtures:", len(res))
 
 
+def fsq_cases():
+    # levels, N, seed   ([8,8,8,5,5,5] and [8,8,8,8,5,5,5,5] are the two the reference instantiates,
+    # model_new/autoencoder.py:59,140; [7,5,3,2] exercises half widths that are not powers of two)
+    return [([8, 8, 8, 5, 5, 5], 2048, 401), ([8, 8, 8, 8, 5, 5, 5, 5], 1024, 402), ([7, 5, 3, 2], 512, 403)]
+
+
+def make_fsq(out):
+    fsq_mod = _load("ref_fsq", os.path.join(REF, "models/model_new/quantizer/fsq.py"))
+    for levels, N, seed in fsq_cases():
+        q = fsq_mod.FSQ(levels=levels)
+        z = torch.from_numpy(gen.normal((N, len(levels)), seed, std=1.5)).requires_grad_(True)
+        g = torch.from_numpy(gen.normal((N, len(levels)), seed + 1000))
+        codes, info = q(z)
+        (codes * g).sum().backward()
+        with torch.no_grad():
+            bounded = q.bound(z.detach())
+            back = q.indices_to_codes(info["indices"])
+        key = "fsq_" + "x".join(str(v) for v in levels)
+        np.savez_compressed(os.path.join(out, key + ".npz"), codes=codes.detach().numpy(), indices=info["indices"].numpy().astype(np.int32),
+                            bounded=bounded.numpy(), dz=z.grad.numpy(), codes_from_indices=back.numpy().astype(np.float32),
+                            codebook_size=np.int64(q.codebook_size), meta=np.array([N, seed], dtype=np.int64))
+        print(key, "codebook", q.codebook_size, "indices[:6]", info["indices"][:6].tolist())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "fsq":  # only the FSQ fixtures (added after the others were committed)
+        make_fsq(HERE)
+        sys.exit(0)
     models, bott, emb = load_reference()
+    make_fsq(HERE)
     make_vq(models, HERE)
     make_bottleneck(models, HERE)
     make_embed(emb, HERE)

@@ -100,6 +100,21 @@ def test_cpu_tensors_are_refused():
     d = vt.TransformerDiscriminator(128, 4, 1, 32, 2, 8, 3, frame_num=4)
     with pytest.raises(vt.hip.HipError):
         d(torch.zeros(1, 3, 4, 32, 32))
+    q = vt.FSQ(levels=[8, 8, 8, 5, 5, 5])
+    for call in (lambda: q(torch.zeros(2, 4, 6)), lambda: q.indices_to_codes(torch.zeros(2, 4, dtype=torch.int32))):
+        with pytest.raises(vt.hip.HipError):
+            call()
+
+
+def test_fsq_host_surface():
+    """FSQ of models/model_new/quantizer/fsq.py:54-75: sizes, non-persistent buffers; the level list is validated by the
+    library itself on the host (no GPU needed for that call)"""
+    q = vt.FSQ(levels=[8, 8, 8, 8, 5, 5, 5, 5])
+    assert q.codebook_size == 2560000 == vt.hip.fsq_codebook_size(q.levels) and q.dim == 8 and len(q.state_dict()) == 0
+    assert q._basis.tolist() == [1, 8, 64, 512, 4096, 20480, 102400, 512000]
+    for bad in ([8, 1], [8] * 9, [2] * 17):
+        with pytest.raises(vt.hip.HipError):
+            vt.hip.fsq_codebook_size(bad)
 
 
 def test_discriminator_and_loss_module_surface():

@@ -169,3 +169,55 @@ def test_c_oracle_codebook_gradient_matches_reference_autograd(case, golden_dir)
     s_b = np.float32(np.float32(0.7) * np.float32(2.0)) / np.float32(np.float32(b * n) * np.float32(d))
     dW = vq_c.codebook_grad(zn, E, wn, idx, s_b)
     np.testing.assert_allclose(dW, f["dE"], rtol=1e-4, atol=1e-6)
+
+
+# ---- finite scalar quantizer (models/model_new/quantizer/fsq.py): oracle/fsq_oracle.c pinned by the reference class's outputs ----
+def _fsq_inputs(levels, N, seed):
+    return gen.normal((N, len(levels)), seed, std=1.5), gen.normal((N, len(levels)), seed + 1000)
+
+
+def _near_rounding_boundary(bounded, ulps=4):
+    """elements whose pre-rounding value sits within a few fp32 ulps of k + 0.5: a 1-ulp difference between two tanh
+    implementations can move them to the neighbouring level (the only tolerated index disagreement)"""
+    frac = np.abs(bounded - np.floor(bounded) - 0.5)
+    return frac <= ulps * np.spacing(np.abs(bounded).astype(np.float32) + 1.0)
+
+
+@pytest.mark.parametrize("case", __import__("tests.golden.make_golden", fromlist=["fsq_cases"]).fsq_cases())
+def test_fsq_c_oracle_matches_reference_class(case):
+    from oracle import fsq_c
+    levels, N, seed = case
+    f = _load("fsq_" + "x".join(str(v) for v in levels))
+    z, up = _fsq_inputs(levels, N, seed)
+    codes, idx, bounded = fsq_c.forward(z, levels)
+    np.testing.assert_allclose(bounded, f["bounded"], rtol=0, atol=5e-7)
+    tie_rows = _near_rounding_boundary(f["bounded"]).any(axis=1)
+    assert tie_rows.mean() < 0.01
+    assert np.array_equal(idx[~tie_rows], f["indices"][~tie_rows])          # bit-exact indices
+    assert np.array_equal(codes[~tie_rows], f["codes"][~tie_rows])          # and codes
+    assert int(f["codebook_size"]) == int(np.prod(levels)) and idx.max() < int(f["codebook_size"]) and idx.min() >= 0
+    # 1 - tanh^2 cancels near saturation, so a 1-ulp tanh difference is an ABSOLUTE error of ~1e-7 * half_l there
+    np.testing.assert_allclose(fsq_c.backward(z, up, levels), f["dz"], rtol=2e-6, atol=1e-6)
+    assert np.array_equal(fsq_c.indices_to_codes(f["indices"], levels), f["codes_from_indices"])
+    # codes -> indices -> codes is the identity on the code lattice
+    assert np.array_equal(fsq_c.indices_to_codes(idx, levels), codes)
+
+
+def test_fsq_constants_match_torch_for_all_small_levels():
+    """half_l / offset / shift exactly as fsq.py:78-80 computes them with torch fp32 ops"""
+    from oracle import fsq_c
+    levels = list(range(2, 18))
+    k = fsq_c.constants(levels)
+    lv = torch.tensor(levels, dtype=torch.int32)
+    half_l = (lv - 1) * (1 + 1e-3) / 2
+    offset = torch.where(lv % 2 == 0, 0.5, 0.0)
+    shift = (offset / half_l).atanh()
+    assert np.array_equal(k["half_l"], half_l.numpy()) and np.array_equal(k["offset"], offset.numpy())
+    # shift = atanh(offset / half_l): the oracle rounds the double-precision value, torch's fp32 atanh is within one ulp of
+    # that (it differs for levels == 12 here); identical for the levels the reference instantiates (5 and 8)
+    sh = shift.numpy()
+    assert np.all(np.abs(k["shift"] - sh) <= np.spacing(sh))
+    for used in (5, 8):
+        assert k["shift"][levels.index(used)] == sh[levels.index(used)]
+    assert np.array_equal(k["half_width"], (lv // 2).float().numpy())
+    assert np.array_equal(k["basis"], torch.cumprod(torch.tensor([1] + levels[:-1]), dim=0).to(torch.int32).numpy())

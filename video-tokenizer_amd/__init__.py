@@ -9,3 +9,4 @@ from .registry import make, models, register  # noqa: F401
 from . import transformer, bottleneck, larp_tokenizer, loss  # noqa: F401  (registers the classes)
 from .larp_tokenizer import LARPTokenizer  # noqa: F401
 from .loss import TransformerDiscriminator, VQLPIPSWithDiscriminator  # noqa: F401
+from .fsq import FSQ  # noqa: F401

@@ -252,3 +252,21 @@ def codebook_entries(indices, codebook, l2_normalized):
     out = torch.empty(idx.numel(), d, device=dev)
     hip.check(hip.lib().vt_vq_gather(hip.ptr(E), hip.ptr(idx), idx.numel(), K, d, hip.ptr(out), None, 0, hip.stream()), "vt_vq_gather")
     return out.reshape(*indices.shape, d)
+
+
+class FiniteScalarQuantize(torch.autograd.Function):
+    """FSQ.forward (models/model_new/quantizer/fsq.py:119-131): one launch per direction, straight-through gradient."""
+
+    @staticmethod
+    def forward(ctx, z, levels):
+        zc = z.contiguous()
+        codes, idx = hip.fsq_forward(zc, levels)
+        ctx.save_for_backward(zc)
+        ctx.levels = levels
+        ctx.mark_non_differentiable(idx)
+        return codes, idx
+
+    @staticmethod
+    def backward(ctx, dcodes, _didx):
+        (z,) = ctx.saved_tensors
+        return hip.fsq_backward(z, dcodes.contiguous().to(z.dtype), ctx.levels), None

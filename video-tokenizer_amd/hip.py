@@ -67,6 +67,10 @@ SIGNATURES = {
     "vt_vq_prep_codebook": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_vq_gather": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "vt_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp]),
+    "vt_fsq_codebook_size": (c_i32, [ctypes.POINTER(c_i32), c_i32, ctypes.POINTER(c_i64)]),
+    "vt_fsq_forward": (c_i32, [c_vp, c_i32, c_i64, c_i32, ctypes.POINTER(c_i32), c_vp, c_vp, c_vp]),
+    "vt_fsq_backward": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, ctypes.POINTER(c_i32), c_vp, c_vp]),
+    "vt_fsq_indices_to_codes": (c_i32, [c_vp, c_i64, c_i32, ctypes.POINTER(c_i32), c_vp, c_i32, c_vp]),
 }
 
 
@@ -353,3 +357,50 @@ def vq_backward(g_rz, gscal, saved, beta=0.25, codebook_w=1.0, l2_normalized=Tru
                                ptr(saved["znorm"]), ptr(E), ptr(saved["wnorm"]), ptr(saved["idx"]), N, K, d, int(l2_normalized),
                                ptr(dz), ptr(dz_pad), ldp, ptr(dW), ptr(ws), stream()), "vt_vq_backward")
     return dz, dz_pad, dW
+
+
+def _levels(levels):
+    return (c_i32 * len(levels))(*[int(v) for v in levels])
+
+
+def _fsq_dtype(t):
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"FSQ kernels take fp32 or bf16, got {t.dtype}")
+    return int(t.dtype == torch.bfloat16)
+
+
+def fsq_codebook_size(levels):
+    """host-only (no GPU needed): prod(levels), with the library's own validation of the level list"""
+    size = c_i64(0)
+    check(lib().vt_fsq_codebook_size(_levels(levels), len(levels), ctypes.byref(size)), "vt_fsq_codebook_size")
+    return size.value
+
+
+def fsq_forward(z, levels, want_indices=True):
+    """z [..., d] fp32/bf16 contiguous -> (codes like z, indices int32 [...])"""
+    require_gpu(z)
+    d = len(levels)
+    assert z.is_contiguous() and z.shape[-1] == d
+    N = z.numel() // d
+    codes = torch.empty_like(z)
+    idx = torch.empty(z.shape[:-1], device=z.device, dtype=torch.int32) if want_indices else None
+    check(lib().vt_fsq_forward(ptr(z), _fsq_dtype(z), N, d, _levels(levels), ptr(codes), ptr(idx), stream()), "vt_fsq_forward")
+    return codes, idx
+
+
+def fsq_backward(z, dcodes, levels):
+    require_gpu(z, dcodes)
+    d = len(levels)
+    assert z.is_contiguous() and dcodes.is_contiguous() and z.shape == dcodes.shape and z.dtype == dcodes.dtype
+    dz = torch.empty_like(z)
+    check(lib().vt_fsq_backward(ptr(z), ptr(dcodes), _fsq_dtype(z), z.numel() // d, d, _levels(levels), ptr(dz), stream()), "vt_fsq_backward")
+    return dz
+
+
+def fsq_indices_to_codes(indices, levels, dtype=torch.float32):
+    require_gpu(indices)
+    d = len(levels)
+    idx = indices.to(torch.int32).contiguous()
+    codes = torch.empty(*idx.shape, d, device=idx.device, dtype=dtype)
+    check(lib().vt_fsq_indices_to_codes(ptr(idx), idx.numel(), d, _levels(levels), ptr(codes), _fsq_dtype(codes), stream()), "vt_fsq_indices_to_codes")
+    return codes
