@@ -234,6 +234,34 @@ int vt_fsq_indices_to_codes(const int32_t* indices, int64_t N, int32_t d, const 
                             int32_t is_bf16, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Glue of the TiTok-style transformer block (models/model_new/base/transformer.py:11-63, rope.py:18-24): the block's
+ * GEMMs, its LayerNorm over D and the attention itself are vt_gemm_nt / vt_layernorm_* / vt_attention_*; these are the
+ * HBM-bound passes in between.  All matrices bf16 row-major, 16-byte aligned; head_dim is 64 (utils.py:6), D = 64 H.
+ *   qkvg [M, 4D]  = to_qkv(x), columns q | k | v | gate (chunk(4), :46), M = B * L rows, row r has position r % L.
+ *   vt_qknorm_rope_fwd: q, k <- rotary(LayerNorm_64(q or k; eps, affine q_w/q_b, k_w/k_b)) (:52-56), v copied; writes
+ *     the packed [M, 3D] operand of vt_attention_fwd.  cos/sin: fp32 [L, 32] = real/imag of freqs_cis (rope.py:27-46,
+ *     95-112), pair j of a head rotates (x[2j], x[2j+1]).
+ *   vt_qknorm_rope_bwd: dqkv [M, 3D] (from vt_attention_bwd) -> columns 0..3D of dqkvg [M, 4D]; parameter gradients
+ *     dq_w, dq_b, dk_w, dk_b fp32 [64] each (any may be NULL); workspace of vt_qknorm_rope_bwd_workspace_bytes().
+ *   vt_sigmoid_gate_fwd: og [M, D] = o * sigmoid(gate) (:61), gate read in place from columns 3D..4D of qkvg.
+ *   vt_sigmoid_gate_bwd: dog -> d_o [M, D] and columns 3D..4D of dqkvg.
+ *   vt_geglu_fwd: a[:, :I] = gelu_erf(h[:, I:2I]) * h[:, :I]  (GEGLU, :11-17), h [M, 2I], a has row stride lda >= I
+ *     (pad columns are not written: zero them once if lda is the 64-padded contraction dim of the next GEMM).
+ *   vt_geglu_bwd: da -> dh [M, 2I].
+ * Rounding follows autocast(bf16): every tensor the reference materialises in bf16 is rounded at the same point.
+ * ------------------------------------------------------------------------------------------ */
+int vt_qknorm_rope_fwd(const void* qkvg, int64_t M, int32_t L, int32_t H, const float* q_w, const float* q_b, const float* k_w,
+                       const float* k_b, float eps, const float* cos_tab, const float* sin_tab, void* qkv_out, vtStream stream);
+size_t vt_qknorm_rope_bwd_workspace_bytes(void);
+int vt_qknorm_rope_bwd(const void* qkvg, const void* dqkv, int64_t M, int32_t L, int32_t H, const float* q_w, const float* k_w,
+                       float eps, const float* cos_tab, const float* sin_tab, void* dqkvg, float* dq_w, float* dq_b, float* dk_w,
+                       float* dk_b, void* workspace, vtStream stream);
+int vt_sigmoid_gate_fwd(const void* o, const void* qkvg, int64_t M, int32_t D, void* og, vtStream stream);
+int vt_sigmoid_gate_bwd(const void* dog, const void* o, const void* qkvg, int64_t M, int32_t D, void* d_o, void* dqkvg, vtStream stream);
+int vt_geglu_fwd(const void* h, int64_t M, int32_t I, void* a, int64_t lda, vtStream stream);
+int vt_geglu_bwd(const void* da, int64_t lda, const void* h, int64_t M, int32_t I, void* dh, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused Adam (+ optional EMA) over flat fp32 buffers: replaces optimizer.step() of torch.optim.Adam
  * (trainers/larp_tokenizer_trainer.py:160-212 builds Adam(lr, betas); :376-377 steps it) and
  * update_ema (trainers/base_trainer.py:769-779), one HBM-bound pass.  n % 4 == 0; step counts from 1;

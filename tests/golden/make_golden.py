@@ -200,14 +200,36 @@ def make_fsq(out):
         print(key, "codebook", q.codebook_size, "indices[:6]", info["indices"][:6].tolist())
 
 
+def make_rope(out):
+    """models/model_new/base/rope.py (pure torch/einops): the 3-axis interleaved rotary table and its application"""
+    rope = _load("ref_rope", os.path.join(REF, "models/model_new/base/rope.py"))
+    res = {}
+    for tokens, grid in ((32, [2, 4, 4]), (1024, [4, 16, 16]), (512, [4, 16, 16])):
+        f = rope.get_freqs(tokens, grid, head_dim=64)                    # complex128 [L, 32]
+        ang = torch.angle(f).numpy()
+        tag = f"freqs_t{tokens}_g" + "x".join(str(v) for v in grid)
+        res[tag + "_shape"] = np.array(f.shape)
+        res[tag + "_sum"] = np.concatenate([checksum(f.real.numpy()), checksum(f.imag.numpy())])
+        step = max(1, f.shape[0] // 64)
+        res[tag + "_real"] = f.real.numpy()[::step][:64]
+        res[tag + "_imag"] = f.imag.numpy()[::step][:64]
+        print(tag, tuple(f.shape), "angle range", ang.min(), ang.max())
+    f = rope.get_freqs(32, [2, 4, 4], head_dim=64)
+    x = torch.from_numpy(gen.normal((2, 64, 3, 64), 501))
+    res["apply_out"] = rope.apply_rotary_emb(x, f).numpy()
+    res["grid_t32"] = rope.get_grid([2, 4, 4], 32).numpy()
+    np.savez_compressed(os.path.join(out, "titok_rope.npz"), **res)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] == "fsq":  # only the FSQ fixtures (added after the others were committed)
-        make_fsq(HERE)
+    if len(sys.argv) > 1 and sys.argv[1] in ("fsq", "rope"):  # only these fixtures (added after the others were committed)
+        {"fsq": make_fsq, "rope": make_rope}[sys.argv[1]](HERE)
         sys.exit(0)
     models, bott, emb = load_reference()
     make_fsq(HERE)
+    make_rope(HERE)
     make_vq(models, HERE)
     make_bottleneck(models, HERE)
     make_embed(emb, HERE)

@@ -71,6 +71,13 @@ SIGNATURES = {
     "vt_fsq_forward": (c_i32, [c_vp, c_i32, c_i64, c_i32, ctypes.POINTER(c_i32), c_vp, c_vp, c_vp]),
     "vt_fsq_backward": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, ctypes.POINTER(c_i32), c_vp, c_vp]),
     "vt_fsq_indices_to_codes": (c_i32, [c_vp, c_i64, c_i32, ctypes.POINTER(c_i32), c_vp, c_i32, c_vp]),
+    "vt_qknorm_rope_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "vt_qknorm_rope_bwd_workspace_bytes": (c_sz, []),
+    "vt_qknorm_rope_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vt_sigmoid_gate_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "vt_sigmoid_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "vt_geglu_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "vt_geglu_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),
 }
 
 
@@ -404,3 +411,65 @@ def fsq_indices_to_codes(indices, levels, dtype=torch.float32):
     codes = torch.empty(*idx.shape, d, device=idx.device, dtype=dtype)
     check(lib().vt_fsq_indices_to_codes(ptr(idx), idx.numel(), d, _levels(levels), ptr(codes), _fsq_dtype(codes), stream()), "vt_fsq_indices_to_codes")
     return codes
+
+
+# ---- glue of the TiTok-style block (csrc/vt_gated.hip) ----
+def qknorm_rope_fwd(qkvg, L, H, q_w, q_b, k_w, k_b, eps, cos, sin):
+    """qkvg bf16 [M, 4 * 64 H] -> packed bf16 [M, 3 * 64 H] (q, k normalised per head and rotated; v copied)"""
+    require_gpu(qkvg, q_w, q_b, k_w, k_b, cos, sin)
+    M = qkvg.shape[0]
+    assert qkvg.dtype == torch.bfloat16 and qkvg.is_contiguous() and qkvg.shape[1] == 4 * 64 * H and cos.shape == (L, 32) == sin.shape
+    out = torch.empty(M, 3 * 64 * H, device=qkvg.device, dtype=torch.bfloat16)
+    check(lib().vt_qknorm_rope_fwd(ptr(qkvg), M, L, H, ptr(q_w), ptr(q_b), ptr(k_w), ptr(k_b), eps, ptr(cos), ptr(sin), ptr(out), stream()),
+          "vt_qknorm_rope_fwd")
+    return out
+
+
+def qknorm_rope_bwd(qkvg, dqkv, L, H, q_w, k_w, eps, cos, sin, dqkvg):
+    """writes columns 0..3D of dqkvg in place; returns (dq_w, dq_b, dk_w, dk_b)"""
+    require_gpu(qkvg, dqkv, dqkvg)
+    M = qkvg.shape[0]
+    assert dqkv.is_contiguous() and dqkvg.is_contiguous() and dqkvg.shape == qkvg.shape and dqkv.shape == (M, 3 * 64 * H)
+    grads = torch.empty(4, 64, device=qkvg.device)
+    ws = _ws(lib().vt_qknorm_rope_bwd_workspace_bytes(), qkvg.device)
+    check(lib().vt_qknorm_rope_bwd(ptr(qkvg), ptr(dqkv), M, L, H, ptr(q_w), ptr(k_w), eps, ptr(cos), ptr(sin), ptr(dqkvg), ptr(grads[0]),
+                                   ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(ws), stream()), "vt_qknorm_rope_bwd")
+    return grads[0], grads[1], grads[2], grads[3]
+
+
+def sigmoid_gate_fwd(o, qkvg):
+    require_gpu(o, qkvg)
+    M, D = o.shape
+    assert o.is_contiguous() and qkvg.shape == (M, 4 * D)
+    og = torch.empty_like(o)
+    check(lib().vt_sigmoid_gate_fwd(ptr(o), ptr(qkvg), M, D, ptr(og), stream()), "vt_sigmoid_gate_fwd")
+    return og
+
+
+def sigmoid_gate_bwd(dog, o, qkvg, dqkvg):
+    """returns d_o; writes columns 3D..4D of dqkvg in place"""
+    require_gpu(dog, o, qkvg, dqkvg)
+    M, D = o.shape
+    assert dog.is_contiguous() and dog.shape == o.shape and dqkvg.shape == qkvg.shape
+    d_o = torch.empty_like(o)
+    check(lib().vt_sigmoid_gate_bwd(ptr(dog), ptr(o), ptr(qkvg), M, D, ptr(d_o), ptr(dqkvg), stream()), "vt_sigmoid_gate_bwd")
+    return d_o
+
+
+def geglu_fwd(h, lda=None):
+    require_gpu(h)
+    M, I2 = h.shape
+    I = I2 // 2
+    lda = I if lda is None else lda
+    a = torch.empty(M, lda, device=h.device, dtype=torch.bfloat16) if lda == I else torch.zeros(M, lda, device=h.device, dtype=torch.bfloat16)
+    check(lib().vt_geglu_fwd(ptr(h), M, I, ptr(a), lda, stream()), "vt_geglu_fwd")
+    return a
+
+
+def geglu_bwd(da, h):
+    require_gpu(da, h)
+    M, I2 = h.shape
+    assert da.shape[0] == M and da.is_contiguous()
+    dh = torch.empty_like(h)
+    check(lib().vt_geglu_bwd(ptr(da), da.shape[1], ptr(h), M, I2 // 2, ptr(dh), stream()), "vt_geglu_bwd")
+    return dh
