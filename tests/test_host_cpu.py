@@ -106,6 +106,26 @@ def test_cpu_tensors_are_refused():
             call()
 
 
+def test_titok_autoencoder_host_surface():
+    """registry names, state-dict layout and rotary tables of the FSQ autoencoder family (model_new/autoencoder.py:8,89,589)"""
+    from oracle import titok_oracle as T
+    assert {"autoencoder_convpatchify", "autoencoder_convpatchify_greatfsq", "autoencoder_large"} <= set(vt.models)
+    m = vt.make({"name": "autoencoder_convpatchify", "args": {"bottleneck": None, "prior_model": None, "input_size": 128, "encoder_depth": 6,
+                                                               "_geometry": dict(in_grid=[8, 32, 32], tokens=32)}})
+    cfg = T.make_cfg("small", frames=8, side=32, tokens=32)
+    sd = T.init_state_dict(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    assert m.encoder.model_layers.ffd_layer[0][1].weight.shape == (2 * 1376, 512) and m.prior_model is None
+    assert m.encoder.proj_out.bias.abs().sum() == 0 and float(m.encoder.model_layers.attn_layer[0].q_norm.weight.mean()) == 1.0
+    cos, sin = vt.titok.rope_tables(1024, [4, 16, 16])
+    ang = T.rope_angles(1024, [4, 16, 16], 64)
+    assert cos.shape == (2048, 32) and torch.equal(cos, torch.cos(ang).float()) and torch.equal(sin, torch.sin(ang).float())
+    assert vt.titok.get_model_dims("large") == (1024, 24, 16, 4.0) and vt.titok.get_model_dims("base_thin") == (1024, 7, 16, 2.0)
+    assert vt.titok.ffd_inner_dim(1024) == 2752
+    with pytest.raises(vt.hip.HipError):
+        m(torch.zeros(2, 3, 8, 32, 32))                      # CPU tensors: no CPU path
+
+
 def test_fsq_host_surface():
     """FSQ of models/model_new/quantizer/fsq.py:54-75: sizes, non-persistent buffers; the level list is validated by the
     library itself on the host (no GPU needed for that call)"""

@@ -221,3 +221,37 @@ def test_fsq_constants_match_torch_for_all_small_levels():
         assert k["shift"][levels.index(used)] == sh[levels.index(used)]
     assert np.array_equal(k["half_width"], (lv // 2).float().numpy())
     assert np.array_equal(k["basis"], torch.cumprod(torch.tensor([1] + levels[:-1]), dim=0).to(torch.int32).numpy())
+
+
+# ---- TiTok-style rotary tables (models/model_new/base/rope.py): oracle/titok_oracle.py pinned by the reference file's outputs ----
+@pytest.mark.parametrize("tokens,grid", [(32, [2, 4, 4]), (1024, [4, 16, 16]), (512, [4, 16, 16])])
+def test_titok_rope_tables_match_reference(tokens, grid):
+    from oracle import titok_oracle as T
+    f = _load("titok_rope")
+    ang = T.rope_angles(tokens, grid, 64)
+    tag = f"freqs_t{tokens}_g" + "x".join(str(v) for v in grid)
+    assert tuple(ang.shape) == tuple(f[tag + "_shape"])
+    re, im = torch.cos(ang).numpy(), torch.sin(ang).numpy()
+    step = max(1, ang.shape[0] // 64)
+    np.testing.assert_allclose(re[::step][:64], f[tag + "_real"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(im[::step][:64], f[tag + "_imag"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(np.concatenate([checksum(re), checksum(im)]), f[tag + "_sum"], rtol=1e-12, atol=1e-9)
+
+
+def test_titok_rotary_application_and_grid_match_reference():
+    from oracle import titok_oracle as T
+    f = _load("titok_rope")
+    assert np.array_equal(T.rope_grid([2, 4, 4], 32).numpy(), f["grid_t32"])
+    x = torch.from_numpy(gen.normal((2, 64, 3, 64), 501))
+    out = T.apply_rotary(x, T.rope_angles(32, [2, 4, 4], 64))
+    np.testing.assert_allclose(out.numpy(), f["apply_out"], rtol=0, atol=1e-7)
+
+
+def test_titok_oracle_fsq_restatement_matches_c_oracle_and_reference():
+    """the differentiable torch FSQ used inside the autoencoder oracle == the pinned C oracle / reference vectors"""
+    from oracle import titok_oracle as T
+    levels, N, seed = [8, 8, 8, 5, 5, 5], 2048, 401
+    f = _load("fsq_8x8x8x5x5x5")
+    z, _ = _fsq_inputs(levels, N, seed)
+    codes, idx, bounded = T.fsq(torch.from_numpy(z), levels)
+    assert np.array_equal(idx.numpy(), f["indices"]) and np.array_equal(codes.numpy(), f["codes"])
