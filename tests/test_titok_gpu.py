@@ -135,7 +135,7 @@ def test_one_gated_layer_matches_oracle(vt):
     cos, sin = vt.titok.rope_tables(32, cfg["grid"])
     dev = [sd[k].clone().cuda().requires_grad_(True) for k in names]
     xd = x.clone().cuda().requires_grad_(True)
-    out = vt.titok.GatedLayer.apply(xd, cos.cuda(), sin.cuda(), H, scale, *dev)
+    out = vt.titok.GatedLayer.apply(xd, cos.cuda(), sin.cuda(), H, scale, None, *dev)
     (out * up.cuda()).sum().backward()
     assert rel(out, ref) < 5e-3
     assert rel(xd.grad, xr.grad) < 2e-2

@@ -157,13 +157,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     }
 }
 
-// 256 threads: t -> (which, w|b, element); fixed summation order over the NBLK partials
+// one wave per output element (which, w|b, e): lane l adds partials l, l + 64, ... in order, then a fixed butterfly
 __global__ __launch_bounds__(256) void qknorm_reduce_kernel(const float* __restrict__ part, int nblk, float* dq_w, float* dq_b, float* dk_w, float* dk_b) {
-    const int t = threadIdx.x;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // t in [0, 256)
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * 256 + t];
+    for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * 256 + t];
+    s = wave_sum(s);
     float* dst = (t >> 6) == 0 ? dq_w : (t >> 6) == 1 ? dq_b : (t >> 6) == 2 ? dk_w : dk_b;
-    if (dst) dst[t & 63] = s;
+    if (dst && lane == 0) dst[t & 63] = s;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -263,7 +264,7 @@ extern "C" int vt_qknorm_rope_bwd(const void* qkvg, const void* dqkv, int64_t M,
     hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(NBLK, 3), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkvg, (const bf16_t*)dqkv, M, L, H, q_w, k_w,
                        eps, cos_tab, sin_tab, (bf16_t*)dqkvg, (float*)workspace);
     VT_CHECK_LAUNCH("vt_qknorm_rope_bwd");
-    hipLaunchKernelGGL(qknorm_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, NBLK, dq_w, dq_b, dk_w, dk_b);
+    hipLaunchKernelGGL(qknorm_reduce_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, NBLK, dq_w, dq_b, dk_w, dk_b);
     VT_CHECK_LAUNCH("vt_qknorm_rope_bwd(reduce)");
     return VT_OK;
 }

@@ -283,7 +283,8 @@ def cast_rows(src, rows=None, rmap=None, ldd=None, dst=None):
     dim = src.shape[-1]
     rows = rows if rows is not None else src.numel() // dim
     ldd = ldd or (dst.stride(0) if dst is not None else dim)
-    dst = torch.zeros(rows, ldd, device=src.device, dtype=torch.bfloat16) if dst is None else dst
+    if dst is None:     # pad columns (ldd > dim) must read as zeros; a dense destination is fully overwritten
+        dst = (torch.zeros if ldd != dim else torch.empty)(rows, ldd, device=src.device, dtype=torch.bfloat16)
     check(lib().vt_cast_rows(ptr(src), rmap or IDENT, rows, dim, ptr(dst), ldd, stream()), "vt_cast_rows")
     return dst
 
@@ -297,8 +298,10 @@ def pack_weight(w, row_perm=None, want_t=True, ldd=None, lddT=None, n_pad=None, 
     N, K = w2.shape
     ldd = ldd or (k_pad or K)
     lddT = lddT or (n_pad or N)
-    wb = torch.zeros(n_pad or N, ldd, device=w.device, dtype=torch.bfloat16)
-    wt = torch.zeros(k_pad or K, lddT, device=w.device, dtype=torch.bfloat16) if want_t else None
+    dense = (n_pad or N) == N and (k_pad or K) == K and ldd == K and lddT == N      # no padding anywhere: fully overwritten
+    alloc = torch.empty if dense else torch.zeros
+    wb = alloc(n_pad or N, ldd, device=w.device, dtype=torch.bfloat16)
+    wt = alloc(k_pad or K, lddT, device=w.device, dtype=torch.bfloat16) if want_t else None
     check(lib().vt_pack_weight(ptr(w2), N, K, ptr(row_perm), ptr(wb), ldd, ptr(wt), lddT, stream()), "vt_pack_weight")
     return wb, wt
 

@@ -72,11 +72,18 @@ def rope_tables(in_tokens, in_grid, head_dim=64, theta=10000.0):
     return torch.from_numpy(np.cos(ang).astype(np.float32)), torch.from_numpy(np.sin(ang).astype(np.float32))
 
 
+def pack_layer_weights(w_qkv, w_out, w_fc1, w_fc2):
+    """bf16 [N, K] copies and [K, N] transposes of a layer's four matrices; fc2's contraction dim padded to a multiple of 64"""
+    with torch.no_grad():
+        return (*hip.pack_weight(w_qkv), *hip.pack_weight(w_out), *hip.pack_weight(w_fc1),
+                *hip.pack_weight(w_fc2, k_pad=_pad64(w_fc2.shape[1])))
+
+
 class GatedLayer(torch.autograd.Function):
     """x -> (x + Attn(x) ; + ffd(.)) * scale for one layer of ResidualAttentionBlock (transformer.py:45-63, 20-29, 82-91)."""
 
     @staticmethod
-    def forward(ctx, x, cos, sin, n_head, scale, w_qkv, q_w, q_b, k_w, k_b, w_out, ln_w, ln_b, w_fc1, w_fc2):
+    def forward(ctx, x, cos, sin, n_head, scale, packs, w_qkv, q_w, q_b, k_w, k_b, w_out, ln_w, ln_b, w_fc1, w_fc2):
         hip.require_gpu(x, cos, sin, w_qkv, w_out, w_fc1, w_fc2)
         B, L, D = x.shape
         M = B * L
@@ -86,10 +93,9 @@ class GatedLayer(torch.autograd.Function):
         ipad = _pad64(inner)
         x2 = x.contiguous().reshape(M, D).float()
         xb = hip.cast_rows(x2)
-        wqkv_b, wqkv_t = hip.pack_weight(w_qkv)
-        wout_b, wout_t = hip.pack_weight(w_out)
-        wfc1_b, wfc1_t = hip.pack_weight(w_fc1)
-        wfc2_b, wfc2_t = hip.pack_weight(w_fc2, k_pad=ipad)          # [D, ipad] and its transpose [ipad, D]
+        if packs is None:                                            # bf16 operand copies (and their transposes for the dgrads)
+            packs = pack_layer_weights(w_qkv, w_out, w_fc1, w_fc2)
+        wqkv_b, wqkv_t, wout_b, wout_t, wfc1_b, wfc1_t, wfc2_b, wfc2_t = packs
         qkvg = hip.gemm_nt(xb, wqkv_b, hip.EPI_BF16)
         qkv = hip.qknorm_rope_fwd(qkvg, L, n_head, q_w, q_b, k_w, k_b, 1e-5, cos, sin)
         o, lse = hip.attention_fwd(qkv, B, L, n_head, 64)
@@ -133,7 +139,7 @@ class GatedLayer(torch.autograd.Function):
         dw_qkv = torch.empty(4 * D, D, device=dev)
         hip.gemm_tn_grouped([dict(A=gb, B=a, out=dw_fc2), dict(A=dh, B=y, out=dw_fc1), dict(A=dx1b, B=og, out=dw_out),
                              dict(A=dqkvg, B=xb, out=dw_qkv)])
-        return (dx.reshape(B, L, D), None, None, None, None, dw_qkv, dq_w, dq_b, dk_w, dk_b, dw_out, d_ln_w, d_ln_b, dw_fc1,
+        return (dx.reshape(B, L, D), None, None, None, None, None, dw_qkv, dq_w, dq_b, dk_w, dk_b, dw_out, d_ln_w, d_ln_b, dw_fc1,
                 dw_fc2[:, :inner].contiguous())
 
 
@@ -206,12 +212,24 @@ class ResidualAttentionBlock(nn.Module):
         self.num_layer, self.heads = num_layer, heads
         self.attn_layer = nn.Sequential(*[Attn(embed_dim, heads) for _ in range(num_layer)])
         self.ffd_layer = nn.Sequential(*[ffd(embed_dim, mlp_ratio) for _ in range(num_layer)])
+        self._pack_cache = {}
+
+    def _packs(self, i):
+        """the layer's bf16 operand copies, re-made only when a weight changed (optimizer step, load_state_dict, .to())"""
+        at, ff = self.attn_layer[i], self.ffd_layer[i]
+        ws = (at.to_qkv.weight, at.out_proj.weight, ff[1].weight, ff[3].weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        hit = self._pack_cache.get(i)
+        if hit is None or hit[0] != key:
+            hit = (key, pack_layer_weights(*ws))
+            self._pack_cache[i] = hit
+        return hit[1]
 
     def forward(self, x, freqs):
         cos, sin = freqs
         for i in range(self.num_layer):
             at, ff = self.attn_layer[i], self.ffd_layer[i]
-            x = GatedLayer.apply(x, cos, sin, self.heads, 1.0 / math.sqrt(i + 1), at.to_qkv.weight, at.q_norm.weight, at.q_norm.bias,
+            x = GatedLayer.apply(x, cos, sin, self.heads, 1.0 / math.sqrt(i + 1), self._packs(i), at.to_qkv.weight, at.q_norm.weight, at.q_norm.bias,
                                  at.k_norm.weight, at.k_norm.bias, at.out_proj.weight, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight)
         return x
 
