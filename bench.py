@@ -91,6 +91,34 @@ def measured_traffic():
         return int(json.load(f)["traffic_bytes_per_launch_mean"])
 
 
+def fsq_autoencoder_step(vt, name, steps, warmup, clips=4):
+    """Secondary figure: forward + backward (L1 reconstruction loss) of an FSQ autoencoder of
+    models/model_new/autoencoder.py at its hard-coded geometry (16x128x128 clips, 1024 + 1024 tokens).  No optimizer step, so the
+    bf16 operand copies of the weights are re-used between steps; `tflops` counts the layers' matrix products only."""
+    from oracle import inputs as gen
+    m = vt.make({"name": name, "args": {"bottleneck": None, "prior_model": None}}).cuda()
+    video = torch.from_numpy(gen.video_clips(clips, 16, 128, 7)).cuda()
+    W, layers, L = m.encoder.width, m.encoder.num_layers, 2048
+    inner = vt.titok.ffd_inner_dim(W)
+    flops = 3 * 2 * layers * (2 * L * W * (4 * W + W + 3 * inner) + 4 * L * L * W)
+
+    def step():
+        for q in m.parameters():
+            q.grad = None
+        (m(video)["pred_frames"] - video).abs().mean().backward()
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"model": name, "parameters_M": round(sum(q.numel() for q in m.parameters()) / 1e6, 1), "clips_per_step": clips,
+            "ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(clips / dt, 2), "tflops": round(clips * flops / dt / 1e12, 1)}
+
+
 def gan_step(vt, model, x, steps, warmup):
     """Secondary figure: the trainer's step with its GAN branch (larp_tokenizer_trainer.py:263-345) --
     tokenizer forward, discriminator update on the detached reconstruction every d_update_freq-th step, generator loss
@@ -158,6 +186,10 @@ def cpu_baseline(c, sd_seed=7):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--fsq-ae", default=None, metavar="NAME",
+                    help="also time fwd+bwd of one of the FSQ autoencoders (autoencoder_large, autoencoder_convpatchify, "
+                         "autoencoder_convpatchify_greatfsq; cfgs/larp_tokenizer_large.yaml:37) at the reference geometry, 4 clips: "
+                         "extra key 'fsq_autoencoder_step'; the headline metric is unchanged")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -266,6 +298,11 @@ def main():
                 res["gan_step"] = gan_step(vt, model, x, a.steps, a.warmup)
             except Exception as e:  # noqa: BLE001
                 res["gan_step"] = {"error": repr(e)}
+        if a.fsq_ae and world == 1:
+            try:
+                res["fsq_autoencoder_step"] = fsq_autoencoder_step(vt, a.fsq_ae, a.steps, a.warmup)
+            except Exception as e:  # noqa: BLE001
+                res["fsq_autoencoder_step"] = {"error": repr(e)}
         if not a.no_roofline:
             try:
                 ach, per, _ = time_dominant_kernel(B, c)
