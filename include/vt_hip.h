@@ -102,7 +102,9 @@ typedef struct {
 int vt_gemm_tn_grouped(const vtGemmTN* problems_host, int32_t n_problems, vtStream stream);
 
 /* Tile generation used by the two GEMM entry points: 0 = auto (192x192x64 tiles, 3-stage LDS-DMA ring, one
- * workgroup per CU, when the problem is at least one tile; else 128x128x64), 1 = force 128, 2 = force 192.
+ * workgroup per CU, when the problem is at least one tile; else 128x128x64), 1 = force 128, 2 = force 192
+ * (NT: persistent, one workgroup per CU walks the tiles), 5 = 192x96 tiles two workgroups per CU (NT only), 6 = 192x192 with
+ * one tile per workgroup (NT only; the A/B partner of the persistent kernel); 3/4 = timing ablations with wrong results.
  * Test/tuning hook; results are identical up to fp32 summation order inside a K-tile (none: same order). */
 int vt_set_gemm_variant(int32_t variant);
 

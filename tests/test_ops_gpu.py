@@ -30,7 +30,7 @@ def _rand(shape, seed, std=1.0):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[1, 2, 5], ids=["tile128", "tile192", "tile192x96"], autouse=False)
+@pytest.fixture(params=[1, 2, 5, 6], ids=["tile128", "tile192", "tile192x96", "tile192_one_tile_per_wg"], autouse=False)
 def gemm_variant(request, hip):
     """run a GEMM test once per tile generation (vt_set_gemm_variant), then restore auto dispatch"""
     hip.check(hip.lib().vt_set_gemm_variant(request.param), "vt_set_gemm_variant")

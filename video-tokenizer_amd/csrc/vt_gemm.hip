@@ -249,7 +249,7 @@ static int g_gemm_variant = 0;  // 0 auto, 1 force 128x128 tiles, 2 force 192x19
 
 // test/tuning hook: choose the tile generation used by vt_gemm_nt / vt_gemm_tn_grouped
 extern "C" int vt_set_gemm_variant(int32_t v) {
-    VT_CHECK_ARG(v >= 0 && v <= 5, "vt_set_gemm_variant: 0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96 (NT only); 3/4: timing experiments, wrong results");
+    VT_CHECK_ARG(v >= 0 && v <= 6, "vt_set_gemm_variant: 0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96 (NT only), 6 = 192x192 one tile per workgroup (NT only); 3/4: timing experiments, wrong results");
     g_gemm_variant = v;
     return VT_OK;
 }
@@ -289,7 +289,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : 0;
+        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant == 6 ? 5 : 0;
         const int half = g_gemm_variant == 5;
         vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half);
         VT_CHECK_LAUNCH("vt_gemm_nt(192)");

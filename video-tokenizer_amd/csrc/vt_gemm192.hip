@@ -97,16 +97,14 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     const int wm = wave / WN, wn = wave % WN;
 
     const int nwg = a.tiles_m * a.tiles_n;
-    const int sid = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * G::TNW;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
-
-    f32x4 acc[6][3];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Ring slot of K-tile t.  The 3-stage kernel is persistent (grid = min(tiles, CUs), workgroup b walks tiles b, b + grid,
+    // ...): K-tile 0 of the NEXT output tile is DMA-ed into slot 2 before the epilogue of the current one -- the staged
+    // epilogue image lives in slots 0-1 -- so its HBM latency runs under the epilogue's stores instead of in front of the
+    // first MFMA (tools/gemm_epilogue_cost.py: ~3 us of the 6-20 us a tile pays outside its main loop).
+    constexpr int ROT = G::NST == 3 ? 2 : 0;
+    auto slot_of = [](int t) { return (t + ROT) % G::NST; };
 
     const int nt = p.K / TK;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
@@ -171,11 +169,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
     unsigned poff[G::P];
-    nt192_piece_offsets<WN>(p.lda, m0, p.M, p.ldb, n0, p.N, tid, poff);
-    const bf16_t* Apanel = A + (int64_t)m0 * p.lda;   // wave-uniform: rows m0.. of A / n0.. of B, K-tile 0
-    const bf16_t* Bpanel = B + (int64_t)n0 * p.ldb;
-    auto issue_tile = [&](int tile) {  // LDS-DMA of K-tile `tile` into ring buffer tile % NST
-        const unsigned dst = sbase + (tile % G::NST) * G::STAGE;
+    const bf16_t *Apanel, *Bpanel;   // wave-uniform: rows m0.. of A / n0.. of B, K-tile 0
+    int m0, n0;
+    auto set_tile = [&](int it) {
+        const int sid = xcd_remap(it, nwg);
+        m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * G::TNW;
+        nt192_piece_offsets<WN>(p.lda, m0, p.M, p.ldb, n0, p.N, tid, poff);
+        Apanel = A + (int64_t)m0 * p.lda;
+        Bpanel = B + (int64_t)n0 * p.ldb;
+    };
+    auto issue_tile = [&](int tile) {  // LDS-DMA of K-tile `tile` into its ring slot
+        const unsigned dst = sbase + slot_of(tile) * G::STAGE;
 #pragma unroll
         for (int k = 0; k < G::P; ++k) nt192_stage_piece<WN>(Apanel + tile * TK, Bpanel + tile * TK, poff, dst, k, wave);
     };
@@ -189,7 +193,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         raw_barrier();
     };
 
+    set_tile(blockIdx.x);
     issue_tile(0);
+    constexpr bool PERSIST = WN == 4;   // the 192x96 experiment stays one tile per workgroup
+    for (int it = blockIdx.x; it < nwg; it = PERSIST ? it + (int)gridDim.x : nwg) {
+    // K-tile 0 of this output tile is already in flight (issued above, or before the previous tile's epilogue)
+    if (it != (int)blockIdx.x) __syncthreads();       // the previous epilogue's LDS image (slots 0-1) has been read back
+    f32x4 acc[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (nt > 1) issue_tile(1);
     if (G::NST > 2 && nt > 2) issue_tile(2);
     if (G::NST > 2 && nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::P) : "memory");
@@ -198,7 +212,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     raw_barrier();
     bf16x8 xa0[6], xb0[3], xa1[6], xb1[3], ya0[6], yb0[3], ya1[6], yb1[3];
     {   // fragments of tile 0
-        const unsigned na0 = sbase + a_off0, na1 = sbase + a_off1, nb0 = sbase + b_off0, nb1 = sbase + b_off1;
+        const unsigned s0 = sbase + slot_of(0) * G::STAGE;
+        const unsigned na0 = s0 + a_off0, na1 = s0 + a_off1, nb0 = s0 + b_off0, nb1 = s0 + b_off1;
         VT_DSR(xb0[0], nb0, 0); VT_DSR(xb0[1], nb0, 2048); VT_DSR(xb0[2], nb0, 4096);
         VT_DSR(xa0[0], na0, 0); VT_DSR(xa0[1], na0, 2048); VT_DSR(xa0[2], na0, 4096);
         VT_DSR(xa0[3], na0, 6144); VT_DSR(xa0[4], na0, 8192); VT_DSR(xa0[5], na0, 10240);
@@ -215,18 +230,18 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         {
             const bool more = t + 1 < nt;
             if (more) sync_for(t + 1);
-            const unsigned nb = sbase + ((more ? t + 1 : t) % G::NST) * G::STAGE;
+            const unsigned nb = sbase + slot_of(more ? t + 1 : t) * G::STAGE;
             const int dma_tile = (t + G::NST < nt && a.dbg != 1) ? t + G::NST : -1;  // goes into the buffer tile t just vacated
-            const unsigned dma_dst = sbase + (t % G::NST) * G::STAGE;
+            const unsigned dma_dst = sbase + slot_of(t) * G::STAGE;
             if (a.dbg != 2) VT_STEP(xa0, xb0, xa1, xb1, ya0, yb0, ya1, yb1, nb, true)
             if (++t == nt) break;
         }
         {   // tile t from set Y, prefetch tile t+1 into set X
             const bool more = t + 1 < nt;
             if (more) sync_for(t + 1);
-            const unsigned nb = sbase + ((more ? t + 1 : t) % G::NST) * G::STAGE;
+            const unsigned nb = sbase + slot_of(more ? t + 1 : t) * G::STAGE;
             const int dma_tile = (t + G::NST < nt && a.dbg != 1) ? t + G::NST : -1;
-            const unsigned dma_dst = sbase + (t % G::NST) * G::STAGE;
+            const unsigned dma_dst = sbase + slot_of(t) * G::STAGE;
             if (a.dbg != 2) VT_STEP(ya0, yb0, ya1, yb1, xa0, xb0, xa1, xb1, nb, true)
             if (++t == nt) break;
         }
@@ -235,6 +250,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 #undef VT_ROW
 #undef VT_STEP
 #undef VT_DMA_ALL
+
+    // every wave is done with the ring: start the next output tile's K-tile 0 into slot 2 (the epilogue below only uses
+    // slots 0-1), then write this tile out
+    const int em0 = m0, en0 = n0;
+    raw_barrier();
+    if constexpr (PERSIST) {
+        if (it + (int)gridDim.x < nwg) {
+            set_tile(it + gridDim.x);
+            if (a.dbg != 1) issue_tile(0);
+        }
+    }
 
     if constexpr (EPI != VT_EPI_F32) {
         if ((p.N & 3) == 0) {
@@ -253,20 +279,19 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 // the pre-activations this thread will need after the read-back: all NIT loads go out now, so their HBM
                 // latency runs under the staging writes and the barrier instead of 20 times in the store loop
                 const int c = tid % UPR, rl = tid / UPR;
-                const int n = n0 + c * 4;
+                const int n = en0 + c * 4;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int row = it * RL + rl;
-                    const int m = m0 + row;
+                    const int m = em0 + row;
                     const bool ok = rl < RL && n < p.N && row < TM && m < p.M;
                     uu_pre[it] = ok ? *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n) : (bf16x4){f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
                 }
             }
-            raw_barrier();                              // every wave is done reading the ring
             f32x4 b4[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int n = n0 + wn * 48 + j * 16 + fq * 4;
+                const int n = en0 + wn * 48 + j * 16 + fq * 4;
                 b4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -282,13 +307,13 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 // next row), so the column sums of the rounded output -- the bias gradient of the Linear whose
                 // pre-activation is `aux` -- fall out of the epilogue instead of a separate pass over M x N
                 const int c = tid % UPR, rl = tid / UPR;
-                const int n = n0 + c * 4;
+                const int n = en0 + c * 4;
                 f32x4 cs = {0.f, 0.f, 0.f, 0.f};
                 if (rl < RL && n < p.N) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const int row = it * RL + rl;
-                        const int m = m0 + row;
+                        const int m = em0 + row;
                         if (row < TM && m < p.M) {
                             const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
                             const bf16x4 uu = uu_pre[it];
@@ -303,21 +328,21 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     float* red = (float*)(smem + TM * STRIDE);       // [RL][TNW], behind the staged image
                     if (rl < RL) *(f32x4*)(red + rl * G::TNW + c * 4) = cs;
                     __syncthreads();
-                    if (tid < G::TNW && n0 + tid < p.N) {
+                    if (tid < G::TNW && en0 + tid < p.N) {
                         float sum = 0.f;
 #pragma unroll
                         for (int r = 0; r < RL; ++r) sum += red[r * G::TNW + tid];
-                        p.colsum_partial[(int64_t)(m0 / TM) * p.N + n0 + tid] = sum;
+                        p.colsum_partial[(int64_t)(em0 / TM) * p.N + en0 + tid] = sum;
                     }
                 }
-                return;
+                continue;
             }
             constexpr int UNR = 2;
 #pragma unroll UNR
             for (int it = 0; it < TM * UPR / G::THREADS; ++it) {
                 const int slot = it * G::THREADS + tid;
                 const int row = slot / UPR, c = slot - row * UPR;
-                const int m = m0 + row, n = n0 + c * 4;
+                const int m = em0 + row, n = en0 + c * 4;
                 if (m >= p.M || n >= p.N) continue;
                 const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
                 bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
@@ -329,21 +354,22 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                         (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
                 }
             }
-            return;
+            continue;
         }
     }
     const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const int m = m0 + wm * 96 + i * 16 + fr;
+        const int m = em0 + wm * 96 + i * 16 + fr;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int n = n0 + wn * 48 + j * 16 + fq * 4;
+            const int n = en0 + wn * 48 + j * 16 + fq * 4;
             if (n >= p.N) continue;
             nt_epilogue<EPI>(p, omap, m, n, acc[i][j]);
         }
     }
+    }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------ TN
@@ -492,6 +518,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
 
 }  // namespace
 
+static int g_num_cus = 256;   // set by vt_gemm192_init from the device properties
+
 // Called by vt_gemm_nt / vt_gemm_tn_grouped (vt_gemm.hip) after argument validation.
 template <int WN>
 static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg) {
@@ -501,7 +529,10 @@ static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg) {
     a.dbg = dbg;
     a.tiles_m = (p.M + TM - 1) / TM;
     a.tiles_n = (p.N + G::TNW - 1) / G::TNW;
-    const dim3 grid(a.tiles_m * a.tiles_n), block(G::THREADS);
+    // WN == 4: persistent, one workgroup per CU walks tiles b, b + grid, ... (dbg 5 = one tile per workgroup, for A/B timing)
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int persist = (WN == 4 && dbg != 5) ? g_num_cus : ntiles;
+    const dim3 grid(ntiles < persist ? ntiles : persist), block(G::THREADS);
     const size_t lds = G::NST * G::STAGE;
     switch (p.epi) {
         case VT_EPI_BF16: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16, WN>), grid, block, lds, s, a); break;
@@ -550,6 +581,11 @@ int vt_gemm192_init() {
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_F32, 2>();
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_DGELU, 2>();
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
+    if (e == hipSuccess) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_num_cus = cus;
+    }
     if (e != hipSuccess) {
         vt_set_error("vt_gemm192_init: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return VT_ERR_LAUNCH;
