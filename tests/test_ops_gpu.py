@@ -432,3 +432,34 @@ def test_pack_weights_grouped_equals_single_packs(hip):
         assert torch.equal(wb[:, :K], src.to(torch.bfloat16)) and torch.all(wb[:, K:] == 0)
         if wt is not None:
             assert torch.equal(wt[:, :N], src.t().to(torch.bfloat16)) and torch.all(wt[:, N:] == 0)
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 768])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "f32res", "dgelu"])
+def test_gemm_nt_persistent_walk_equals_one_tile_per_workgroup(hip, K, epi):
+    """the persistent 192x192 kernel (a workgroup walks 2-3 tiles, the next tile's first K-tile is DMA-ed during the epilogue) must
+    give bit-identical results to the same kernel launched one tile per workgroup, for 1, 2, 3 and 12 K-tiles, ragged M and N
+    (edge tiles first / last in a workgroup's walk), every epilogue; and agree with integer-exact fp32 math"""
+    M, N = 192 * 31 + 77, 192 * 17 + 52                      # 32 x 18 = 576 tiles on 256 workgroups
+    g = torch.Generator().manual_seed(K)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16).cuda()
+    B = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16).cuda()
+    res = torch.randint(-8, 9, (M, N), generator=g).float().cuda()
+    aux = (torch.randint(-6, 7, (M, N), generator=g).float() / 4).to(torch.bfloat16).cuda()
+    kw = {"bf16": dict(epi=hip.EPI_BF16), "gelu": dict(epi=hip.EPI_BF16_GELU), "f32res": dict(epi=hip.EPI_F32, residual=res),
+          "dgelu": dict(epi=hip.EPI_BF16_DGELU, aux=aux)}[epi]
+    outs = {}
+    try:
+        for v in (2, 6):
+            hip.check(hip.lib().vt_set_gemm_variant(v), "vt_set_gemm_variant")
+            o = hip.gemm_nt(A, B, **kw)
+            outs[v] = [t.clone() for t in (o if isinstance(o, tuple) else (o,))]
+    finally:
+        hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")
+    for a, b in zip(outs[2], outs[6]):
+        assert torch.equal(a, b)
+    exact = A.float() @ B.float().t()                           # small integers: exact in fp32, and in bf16 up to |x| <= 256
+    if epi == "bf16":
+        assert torch.equal(outs[2][0].float(), exact.to(torch.bfloat16).float())
+    if epi == "f32res":
+        assert torch.equal(outs[2][0], exact + res)
