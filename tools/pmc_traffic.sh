@@ -10,21 +10,19 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 python3 - <<PY
 import csv, glob, json, collections
 def load(d, name):
+    # launch order = shape order of tools/gemm_pmc.py, 4 launches per shape (the persistent kernel has one grid size for all)
     f = glob.glob(f"$R/gpurun_out/{d}/*/*counter_collection.csv")[0]
-    out = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "gemm_nt192_kernel<0" in r["Kernel_Name"] and r["Counter_Name"] == name:
-            out[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
-    return out
+    rows = [r for r in csv.DictReader(open(f)) if "gemm_nt192_kernel<0" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    vals = [float(r["Counter_Value"]) for r in rows]
+    assert len(vals) == 16, len(vals)
+    return [vals[4 * i:4 * i + 4] for i in range(4)]
 fe, wr = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 M, D = 12288, 768
 shapes = [(M, 3 * D, D), (M, D, 4 * D), (M, D, D), (M, D, 3 * D)]
 res = []
-for (m, n, k) in shapes:
-    grid = ((m + 191) // 192) * ((n + 191) // 192) * 512
-    f = fe[grid]; w = wr[grid]
-    # N = 768 shapes share one grid size: split the samples in launch order (4 per shape)
-    res.append({"M": m, "N": n, "K": k, "grid": grid, "fetch_kb_samples": f, "write_kb_samples": w})
+for i, (m, n, k) in enumerate(shapes):
+    res.append({"M": m, "N": n, "K": k, "fetch_kb_samples": fe[i], "write_kb_samples": wr[i]})
 json.dump(res, open("$R/gpurun_out/pmc_traffic_raw.json", "w"), indent=1)
 print(json.dumps(res)[:1500])
 PY

@@ -22,7 +22,7 @@ def _newer(a, b):
 
 def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
-    deps = [os.path.join(CSRC, "vt_common.h"), os.path.join(HERE, "..", "include", "vt_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "vt_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:

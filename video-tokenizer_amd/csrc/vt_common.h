@@ -107,6 +107,15 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Streaming (non-temporal) global accesses for data that is touched once per kernel -- GEMM outputs, the residual and
+// pre-activation operands of an epilogue: they should not displace the A / B panels that 4-16 neighbouring tiles re-read
+// from the XCD's 4 MB L2 (PMC: the GELU-epilogue GEMM fetched 7x its algorithmic bytes with ordinary stores).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ void st_stream(bf16x4* p, bf16x4 v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, v), (u32x2_t*)p); }
+__device__ __forceinline__ void st_stream(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ bf16x4 ld_stream(const bf16x4* p) { return __builtin_bit_cast(bf16x4, __builtin_nontemporal_load((const u32x2_t*)p)); }
+__device__ __forceinline__ f32x4 ld_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
 __device__ __forceinline__ float round_bf16(float x) { return (float)((bf16_t)x); }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     const int row = it * RL + rl;
                     const int m = em0 + row;
                     const bool ok = rl < RL && n < p.N && row < TM && m < p.M;
-                    uu_pre[it] = ok ? *(const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n) : (bf16x4){f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+                    uu_pre[it] = ok ? ld_stream((const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n)) : (bf16x4){f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
                 }
             }
             f32x4 b4[3];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                             const bf16x4 uu = uu_pre[it];
                             const bf16x4 r = {f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
                                               f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))};
-                            *(bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = r;
+                            st_stream((bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), r);
                             cs += (f32x4){bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
                         }
                     }
@@ -347,11 +347,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
                 bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
                 if constexpr (EPI == VT_EPI_BF16) {
-                    *(bf16x4*)o = h;
+                    st_stream((bf16x4*)o, h);
                 } else {
-                    *(bf16x4*)o = h;
-                    *(bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n) =
-                        (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
+                    st_stream((bf16x4*)o, h);
+                    st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n),
+                              (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))});
                 }
             }
             continue;
