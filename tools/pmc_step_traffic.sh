@@ -14,7 +14,7 @@ def load(d, name):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
-            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+            k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", ""))[:70]
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     return agg
 fe, wr = load("pmc_step_fetch", "FETCH_SIZE"), load("pmc_step_write", "WRITE_SIZE")

@@ -116,6 +116,21 @@ __device__ __forceinline__ void st_stream(f32x4* p, f32x4 v) { __builtin_nontemp
 __device__ __forceinline__ bf16x4 ld_stream(const bf16x4* p) { return __builtin_bit_cast(bf16x4, __builtin_nontemporal_load((const u32x2_t*)p)); }
 __device__ __forceinline__ f32x4 ld_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }
 
+// the same for any 4 / 8 / 16-byte vector type (LayerNorm rows are 8- or 16-byte per lane depending on the width)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+template <typename T>
+__device__ __forceinline__ void st_stream_any(T* p, const T& v) {
+    if constexpr (sizeof(T) == 16) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)p);
+    else if constexpr (sizeof(T) == 8) __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, v), (u32x2_t*)p);
+    else __builtin_nontemporal_store(__builtin_bit_cast(unsigned, v), (unsigned*)p);
+}
+template <typename T>
+__device__ __forceinline__ T ld_stream_any(const T* p) {
+    if constexpr (sizeof(T) == 16) return __builtin_bit_cast(T, __builtin_nontemporal_load((const u32x4_t*)p));
+    else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_nontemporal_load((const u32x2_t*)p));
+    else return __builtin_bit_cast(T, __builtin_nontemporal_load((const unsigned*)p));
+}
+
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
 __device__ __forceinline__ float round_bf16(float x) { return (float)((bf16_t)x); }

@@ -358,6 +358,50 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         }
     }
     const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
+    if constexpr (EPI == VT_EPI_F32 && WN == 4) {
+        if ((p.N & 3) == 0) {
+            // fp32 outputs leave through LDS as well, 96 rows (one wave row) at a time: [96][192] fp32 image, row stride
+            // +16 B.  Read back row-major, a wave's load / store instruction covers 768 contiguous bytes of the residual and
+            // of the output instead of sixteen 64-byte pieces.  The fp32 output is the residual stream, which the next
+            // kernel (a LayerNorm) reads straight away: ordinary stores measured better than streaming ones here.
+            constexpr int FSTRIDE = TN_ * 4 + 16;
+            f32x4 b4[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int n = en0 + wn * 48 + j * 16 + fq * 4;
+                b4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (hf) __syncthreads();
+                if (wm == hf) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            f32x4 v = acc[i][j] + b4[j];
+                            if (p.round_bf16) v = (f32x4){round_bf16(v[0]), round_bf16(v[1]), round_bf16(v[2]), round_bf16(v[3])};
+                            *(f32x4*)(smem + (i * 16 + fr) * FSTRIDE + (wn * 48 + j * 16 + fq * 4) * 4) = v;
+                        }
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int u = 0; u < 96 * 48 / G::THREADS; ++u) {
+                    const int slot = u * G::THREADS + tid;
+                    const int row = slot / 48, c = slot - row * 48;
+                    const int m = em0 + hf * 96 + row, n = en0 + c * 4;
+                    if (m >= p.M || n >= p.N) continue;
+                    f32x4 v = *(const f32x4*)(smem + row * FSTRIDE + c * 16);
+                    const int64_t orow = omap(m);
+                    if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldr + n);
+                    if (p.rowmod) v += *(const f32x4*)(p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n);
+                    *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+                    if (p.out2) st_stream((bf16x4*)((bf16_t*)p.out2 + orow * p.ldo2 + n), (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])});
+                }
+            }
+            continue;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int m = em0 + wm * 96 + i * 16 + fr;
