@@ -279,11 +279,19 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     // auto dispatch (measured on MI355X: tools/gemm_bench.py, tools/gemm_disc_shapes.py): the 192x192 3-stage kernel is
     // ahead whenever its tiles fill whole rounds of the 256 CUs (every tokenizer shape: 256 / 768 / 1024 tiles).  Shapes
     // that leave its last round mostly empty (the discriminator's M = 8 x 1025, N = 384 / 1152: 86 or 258 tiles) finish
-    // sooner on 128x128 tiles, two workgroups per CU; a round of those costs ~0.95 of a 192-round.
+    // sooner on 128x128 tiles, two workgroups per CU.
     bool big = g_gemm_variant >= 2 || p.colsum_partial;
     if (g_gemm_variant == 0 && !big && p.N >= 192 && p.M >= 192) {
+        // cost in units of one full round of 192x192 tiles (256 workgroups, one per CU).  A partly filled last round of
+        // that kernel costs a whole round; the 128x128 kernel runs two workgroups per CU (512 per round, a round ~1.05 of
+        // a 192-round on equal work), and its last round is cheap while it leaves one workgroup per CU
+        // (tools/gemm_disc_shapes.py, gemm_lastblock_shapes.py, gemm_fsq_shapes.py: the rule picks the faster kernel on
+        // every shape measured there).
         const long t192 = (long)((p.M + 191) / 192) * ((p.N + 191) / 192), t128 = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-        const double c192 = (double)((t192 + 255) / 256), c128 = 0.95 * (double)((t128 + 511) / 512);
+        const double c192 = (double)((t192 + 255) / 256);
+        const long rem = t128 % 512;
+        const double last = rem == 0 ? 0.0 : rem <= 256 ? 0.6 : 0.6 + 0.4 * (double)(rem - 256) / 256.0;
+        const double c128 = 1.05 * ((double)(t128 / 512) + last);
         big = c192 <= c128;
     }
     if (big) {
