@@ -108,6 +108,79 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
 
     // ---- epilogue: acc[i][j][r] = C[m0 + wr*64 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
     const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
+    if ((p.N & 3) == 0) {
+        // Outputs leave through LDS, like the 192x192 kernel's: written in the MFMA layout (a lane owns 4 consecutive columns
+        // of 16 different rows), read back row-major so that a store instruction covers whole 256- / 512-byte row pieces.
+        // The loop's last barrier has retired every read of the operand ring.
+        f32x4 b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + fq * 4;
+            b4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (EPI != VT_EPI_F32) {
+            constexpr int STRIDE = BN * 2 + 8;   // bytes; +8: the 16 rows of a ds_write_b64 group fall on different bank pairs
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[i][j] + b4[j];
+                    *(bf16x4*)(smem + (wr * 64 + i * 16 + fr) * STRIDE + (wc * 16 + j * 4 + fq) * 8) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                }
+            __syncthreads();
+#pragma unroll 2
+            for (int u = 0; u < BM * (BN / 4) / 256; ++u) {
+                const int slot = u * 256 + tid;
+                const int row = slot >> 5, c = slot & 31;
+                const int m = m0 + row, n = n0 + c * 4;
+                if (m >= p.M || n >= p.N) continue;
+                const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
+                bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
+                if constexpr (EPI == VT_EPI_BF16) {
+                    st_stream((bf16x4*)o, h);
+                } else if constexpr (EPI == VT_EPI_BF16_GELU) {
+                    st_stream((bf16x4*)o, h);
+                    st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n),
+                              (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))});
+                } else {
+                    const bf16x4 uu = ld_stream((const bf16x4*)((const bf16_t*)p.aux + (int64_t)m * p.ldaux + n));
+                    st_stream((bf16x4*)o, (bf16x4){f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
+                                                   f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))});
+                }
+            }
+        } else {
+            constexpr int FSTRIDE = BN * 4 + 16;  // fp32 image of 64 rows (one wave row) at a time
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (hf) __syncthreads();
+                if (wr == hf) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 v = acc[i][j] + b4[j];
+                            if (p.round_bf16) v = (f32x4){round_bf16(v[0]), round_bf16(v[1]), round_bf16(v[2]), round_bf16(v[3])};
+                            *(f32x4*)(smem + (i * 16 + fr) * FSTRIDE + (wc * 64 + j * 16 + fq * 4) * 4) = v;
+                        }
+                }
+                __syncthreads();
+#pragma unroll 2
+                for (int u = 0; u < 64 * (BN / 4) / 256; ++u) {
+                    const int slot = u * 256 + tid;
+                    const int row = slot >> 5, c = slot & 31;
+                    const int m = m0 + hf * 64 + row, n = n0 + c * 4;
+                    if (m >= p.M || n >= p.N) continue;
+                    f32x4 v = *(const f32x4*)(smem + row * FSTRIDE + c * 16);
+                    const int64_t orow = omap(m);
+                    if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldr + n);
+                    if (p.rowmod) v += *(const f32x4*)(p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n);
+                    *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+                    if (p.out2) st_stream((bf16x4*)((bf16_t*)p.out2 + orow * p.ldo2 + n), (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])});
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wr * 64 + i * 16 + fr;
