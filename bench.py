@@ -3,7 +3,7 @@ all-reduce when N > 1) on synthetic 16x128x128 clips -- BASELINE.json config[1]:
 cfgs/larp_tokenizer.yaml base geometry (pt2 p16, 12+12 blocks, 1024 latent tokens, d=24, K=8192),
 bs=8 per GPU, bf16 MFMA with fp32 accumulate, `LARPTokenizer(bottleneck_type='vq')`.
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W]          (N > 1 without a launcher: spawns its own N rank processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" = model(data) -> L1 reconstruction loss + 0.1*loss_q (the model-side part of
@@ -29,10 +29,26 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MIC
 def yaml_model_args(cfg_name):
     """Model args of the benchmark workload = cfgs/larp_tokenizer.yaml surface with the --opts the SURVEY
     prescribes (model.name larp_tokenizer, bottleneck_type vq, input_size 128)."""
-    from oracle.larp_oracle import make_cfg
-    c = make_cfg(cfg_name)
-    from tests.test_model_gpu import spec_from_cfg
-    return c, spec_from_cfg(c, stochastic=True)  # yaml default: stochastic sampling, tau 0.03
+    from video_tokenizer_amd.config import geometry, model_spec
+    c = geometry(cfg_name)
+    return c, model_spec(c, stochastic=True)  # yaml default: stochastic sampling, tau 0.03
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N rank processes ourselves
+    (the reference does the same with mp.spawn, train.py:162-169), as a `torch.distributed.run` CHILD process -- this
+    parent has not touched the GPU and never execs.  Rank 0's JSON line passes through on stdout; the exit code is the
+    child's (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    return subprocess.call(cmd, env=env)
 
 
 def flops_per_clip(c):
@@ -95,9 +111,8 @@ def fsq_autoencoder_step(vt, name, steps, warmup, clips=4):
     """Secondary figure: forward + backward (L1 reconstruction loss) of an FSQ autoencoder of
     models/model_new/autoencoder.py at its hard-coded geometry (16x128x128 clips, 1024 + 1024 tokens).  No optimizer step, so the
     bf16 operand copies of the weights are re-used between steps; `tflops` counts the layers' matrix products only."""
-    from oracle import inputs as gen
     m = vt.make({"name": name, "args": {"bottleneck": None, "prior_model": None}}).cuda()
-    video = torch.from_numpy(gen.video_clips(clips, 16, 128, 7)).cuda()
+    video = torch.from_numpy(vt.config.synthetic_clips(clips, 16, 128, 7)).cuda()
     W, layers, L = m.encoder.width, m.encoder.num_layers, 2048
     inner = vt.titok.ffd_inner_dim(W)
     flops = 3 * 2 * layers * (2 * L * W * (4 * W + W + 3 * inner) + 4 * L * L * W)
@@ -165,7 +180,7 @@ def gan_step(vt, model, x, steps, warmup):
 def cpu_baseline(c, sd_seed=7):
     """The oracle (CPU restatement, fp32, reference semantics) timed on this host's cores: ONE clip of the
     same workload, forward + backward, stochastic=False index path (multinomial is not the cost)."""
-    from oracle import inputs as gen
+    from oracle import inputs as gen   # the checker's own generator: same bytes as config.synthetic_clips
     from oracle import larp_oracle as O
     try:
         ncpu = len(os.sched_getaffinity(0))
@@ -204,12 +219,31 @@ def main():
                     help="rehearsal of the N > 1 code path on one GPU: process group, DataParallelTokenizer, barriers and the MAX all-reduce at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher / rendezvous rehearsal only: every rank joins the process group (gloo when there is no GPU), "
+                         "barrier + MAX all-reduce, rank 0 prints one JSON line; no model is built")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:     # bare `python bench.py --gpus N`: be our own launcher
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if a.rehearse_launch:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        gpu = torch.cuda.device_count() > local
+        dist.init_process_group("nccl" if gpu else "gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], dtype=torch.float64, device=torch.device("cuda", local) if gpu else "cpu")
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "backend": dist.get_backend(), "max_rank": int(t.item())}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or a.force_dist
@@ -220,7 +254,6 @@ def main():
 
     import video_tokenizer_amd as vt
     from video_tokenizer_amd.parallel import DataParallelTokenizer
-    from oracle import inputs as gen  # synthetic data generator only (inputs, not a checker)
 
     c, spec = yaml_model_args(a.config)
     torch.manual_seed(1234 + rank)
@@ -238,7 +271,7 @@ def main():
         opt = None
 
     B = a.batch
-    x = torch.from_numpy(gen.video_clips(B, c["frame_num"], c["input_size"], 100 + rank)).to(dev)
+    x = torch.from_numpy(vt.config.synthetic_clips(B, c["frame_num"], c["input_size"], 100 + rank)).to(dev)
 
     def step():
         out = net(x)
@@ -260,11 +293,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    host = []
     for _ in range(a.steps):
-        h0 = time.perf_counter()
         loss = step()
-        host.append(time.perf_counter() - h0)  # host-side enqueue time of the step (no sync inside)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -275,6 +305,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(loss).item(), "loss is not finite"
+    # host-side cost of ENQUEUEING one step, measured outside the timed region on an empty queue (a sync before each probe
+    # step): inside the timed loop the host runs ahead until the HIP queue is full and then measures back-pressure instead
+    host = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        step()
+        host.append(time.perf_counter() - h0)
+    torch.cuda.synchronize()
 
     if rank == 0:
         clips_s = world * B * a.steps / dt

@@ -77,6 +77,12 @@ typedef struct {
                                                 sums of the bf16-rounded output over rows [192 t, 192 t + 192) (fixed
                                                 order, no atomics).  vt_sum_slabs over the rows gives the bias gradient
                                                 of the Linear whose pre-activation is `aux`, without re-reading `out` */
+    int32_t tile;                            /* tile generation for THIS call: 0 = automatic (use this; 192x192x64 tiles on a
+                                                3-stage LDS-DMA ring, one persistent workgroup per CU, when the problem fills
+                                                them, else 128x128x64).  Tests / tuning: 1 = force 128, 2 = force 192, 5 = 192x96
+                                                two workgroups per CU, 6 = 192x192 one tile per workgroup, 3/4 = timing
+                                                ablations with WRONG results.  Results do not depend on the choice (same fp32
+                                                summation order).  The library keeps no such setting between calls */
 } vtGemmNT;
 
 int vt_gemm_nt(const vtGemmNT* p_host, vtStream stream);
@@ -97,16 +103,11 @@ typedef struct {
     float* out; int64_t ldo;
     int32_t p_lim, q_lim;
     const int32_t* row_perm;
+    int32_t tile;               /* problem 0's value selects the tile generation of the launch: 0 = automatic, 1 = 128x128, 2 = 192x192 */
 } vtGemmTN;
 
 int vt_gemm_tn_grouped(const vtGemmTN* problems_host, int32_t n_problems, vtStream stream);
 
-/* Tile generation used by the two GEMM entry points: 0 = auto (192x192x64 tiles, 3-stage LDS-DMA ring, one
- * workgroup per CU, when the problem is at least one tile; else 128x128x64), 1 = force 128, 2 = force 192
- * (NT: persistent, one workgroup per CU walks the tiles), 5 = 192x96 tiles two workgroups per CU (NT only), 6 = 192x192 with
- * one tile per workgroup (NT only; the A/B partner of the persistent kernel); 3/4 = timing ablations with wrong results.
- * Test/tuning hook; results are identical up to fp32 summation order inside a K-tile (none: same order). */
-int vt_set_gemm_variant(int32_t variant);
 
 
 /* ------------------------------------------------------------------------------------------

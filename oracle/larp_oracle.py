@@ -264,12 +264,15 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
     return {"pred_frames": pred, **out}
 
 
-def init_state_dict(cfg, seed=1234, zero_head=False):
+def init_state_dict(cfg, seed=1234, zero_head=False, query_std=0.02):
     """Build-owned deterministic weights in the reference state-dict layout (shapes per
     larp_tokenizer.py:110,128,141,157,173,177,209-210,217,237 + timm Block names).
     Distributions follow initialize_weights (:249-328) but values come from
     oracle/inputs.py, not torch RNG; the head is xavier unless zero_head (the
-    reference zero-inits it, :327-328, which makes every gradient but the head's zero)."""
+    reference zero-inits it, :327-328, which makes every gradient but the head's zero).
+    `query_std`: std of encoder_latent_query_embed.  The reference's 0.02 (:281) leaves the latent queries of a freshly
+    initialised model nearly identical, so every token quantises to the same 1-6 codes; parity tests pass 1.0 so that the
+    end-to-end comparison exercises many codebook rows (a trained model's queries are spread too)."""
     from . import inputs as gen
     D = cfg["hidden"]
     pt, ps = cfg["temporal_patch_size"], cfg["patch_size"]
@@ -291,7 +294,7 @@ def init_state_dict(cfg, seed=1234, zero_head=False):
     sd["x_embedder.proj.weight"] = T(gen.xavier_uniform((D, 3, pt, ps, ps), nxt()))
     sd["x_embedder.proj.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
     sd["encoder_patch_pe"] = T(sincos_3d(D, th, tt)).float().reshape(1, nv, D)
-    sd["encoder_latent_query_embed"] = T(gen.normal((nq, D), nxt(), 0.02))
+    sd["encoder_latent_query_embed"] = T(gen.normal((nq, D), nxt(), query_std))
     sd["decoder_latent_pe"] = T(sincos_1d(D, np.arange(nq), cfg.get("latent_pe_scale_factor", 10000))).float().reshape(1, nq, D)
     sd["decoder_patch_query_embed"] = T(sincos_3d(D, th, tt)).float().reshape(1, nv, D)
     sd["decoder_patch_query_token_type_embed"] = T(gen.normal((1, 1, D), nxt(), 0.02))

@@ -223,7 +223,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.vt_abi_version() == 2
+    assert lib.vt_abi_version() == 3
     # argument validation runs on the host before any launch: bad arguments give a code and a message, no GPU needed
     p = vt.hip.GemmNT()
     assert lib.vt_gemm_nt(ctypes.byref(p), None) == -1
@@ -309,8 +309,29 @@ def test_plain_c_client_links_against_the_c_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
-    assert lines[0] == "abi 2"
+    assert lines[0] == "abi 3"
     assert lines[1].startswith("gemm_nt rc -1 msg vt_gemm_nt: null operand")
     assert lines[2].startswith("create rc 0 stages 5 ws ") and int(lines[2].split()[-1]) > 1 << 20
     assert lines[3].startswith("bad create rc -1") and "head_dim" in lines[3]
     assert lines[4].startswith("stack rc 0 ws ")
+
+
+def test_product_geometry_table_and_synthetic_clips_equal_the_checkers():
+    """bench.py takes its geometry table, registry spec and synthetic clips from video-tokenizer_amd/config.py; the oracle
+    keeps its own copies (it must not import the product): both must describe the same configs and produce the same bytes."""
+    from oracle import inputs as gen
+    C = vt.config
+    assert set(C.GEOMETRIES) == set(O.CONFIGS)
+    for n in O.CONFIGS:
+        assert C.geometry(n) == O.make_cfg(n), n
+    assert C.geometry("tiny", bottleneck_token_num=37) == O.make_cfg("tiny", bottleneck_token_num=37)
+    for (b, t, s, seed) in [(2, 4, 32, 11), (1, 2, 64, 3), (3, 16, 16, 100)]:
+        assert np.array_equal(C.synthetic_clips(b, t, s, seed), gen.video_clips(b, t, s, seed))
+    spec = C.model_spec(C.geometry("B"), stochastic=True)
+    assert spec["name"] == "larp_tokenizer" and spec["args"]["bottleneck_type"] == "vq" and spec["args"]["bottleneck"]["args"]["regularizer"]["args"]["stochastic"] is True
+    # bench.py touches oracle/ only inside its cpu_baseline() leg, and tests/ nowhere
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    start, end = src.index("def cpu_baseline"), src.index("\ndef main")
+    outside = src[:start] + src[end:]
+    assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", outside, re.M)
+    assert re.search(r"^\s*from oracle import", src[start:end], re.M)

@@ -32,10 +32,10 @@ def _rand(shape, seed, std=1.0):
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.fixture(params=[1, 2, 5, 6], ids=["tile128", "tile192", "tile192x96", "tile192_one_tile_per_wg"], autouse=False)
 def gemm_variant(request, hip):
-    """run a GEMM test once per tile generation (vt_set_gemm_variant), then restore auto dispatch"""
-    hip.check(hip.lib().vt_set_gemm_variant(request.param), "vt_set_gemm_variant")
+    """run a GEMM test once per tile generation (hip.GEMM_TILE -> vtGemmNT.tile), then restore auto dispatch"""
+    hip.GEMM_TILE = request.param
     yield request.param
-    hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")
+    hip.GEMM_TILE = 0
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (256, 24, 768), (130, 1000, 192)])
@@ -387,12 +387,17 @@ def test_vq_stochastic_mode_matches_softmax_distribution(hip):
     # a different seed gives a different draw
     o2 = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 2, inv_tau=1.0 / 0.3, seed=99)
     assert (o2["idx"] != o["idx"]).float().mean() > 0.5
+    # consecutive per-forward counters must give unrelated noise: with the counter XORed into the token index, call s + 1
+    # re-used call s's noise vectors permuted over tokens (token t of call s == token t ^ s ^ (s + 1) of call s + 1)
+    o3 = hip.vq_forward(torch.from_numpy(z).cuda(), torch.from_numpy(W).cuda(), 2, inv_tau=1.0 / 0.3, seed=1235)
+    perm = torch.arange(N, device="cuda") ^ (1234 ^ 1235)
+    assert (o3["idx"][perm] != o["idx"]).float().mean() > 0.5
 
 
 @pytest.mark.parametrize("M,N,K,variant", [(200, 320, 128, 2), (700, 768, 192, 2), (400, 96, 64, 5)])
 def test_gemm_nt_dgelu_fused_column_sums(hip, M, N, K, variant):
     """vtGemmNT.colsum_partial: per-192-row column sums of the rounded output, out of the epilogue (fc1 bias gradient)"""
-    hip.check(hip.lib().vt_set_gemm_variant(variant), "vt_set_gemm_variant")
+    hip.GEMM_TILE = variant
     try:
         A, B = bf(_rand((M, K), 91, 0.5)), bf(_rand((N, K), 92, 0.5))
         u = bf(_rand((M, N), 93))
@@ -406,7 +411,7 @@ def test_gemm_nt_dgelu_fused_column_sums(hip, M, N, K, variant):
         np.testing.assert_allclose(part.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(part.sum(0).cpu().numpy(), hip.colsum(out).cpu().numpy(), rtol=1e-5, atol=1e-3)
     finally:
-        hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")
+        hip.GEMM_TILE = 0
 
 
 def test_pack_weights_grouped_equals_single_packs(hip):
@@ -451,11 +456,11 @@ def test_gemm_nt_persistent_walk_equals_one_tile_per_workgroup(hip, K, epi):
     outs = {}
     try:
         for v in (2, 6):
-            hip.check(hip.lib().vt_set_gemm_variant(v), "vt_set_gemm_variant")
+            hip.GEMM_TILE = v
             o = hip.gemm_nt(A, B, **kw)
             outs[v] = [t.clone() for t in (o if isinstance(o, tuple) else (o,))]
     finally:
-        hip.check(hip.lib().vt_set_gemm_variant(0), "vt_set_gemm_variant")
+        hip.GEMM_TILE = 0
     for a, b in zip(outs[2], outs[6]):
         assert torch.equal(a, b)
     exact = A.float() @ B.float().t()                           # small integers: exact in fp32, and in bf16 up to |x| <= 256

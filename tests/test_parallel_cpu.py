@@ -73,3 +73,26 @@ def test_grad_reducer_world2_gloo():
         assert ok_mean, "gradient mean over ranks is wrong"
         assert covered, "buckets do not tile the flat gradient buffer"
         assert nb >= 2 and nparams == 57
+
+
+def test_bench_spawns_its_own_ranks_and_reaches_the_process_group():
+    """`python bench.py --gpus 2` with no launcher environment (how the driver may call it): bench.py starts two rank
+    processes itself (torch.distributed.run child, 127.0.0.1 rendezvous) before touching any GPU; with --rehearse-launch each
+    rank joins the group (gloo here: no GPU), passes a barrier and a MAX all-reduce, and rank 0 prints ONE JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r == {"rehearsal": True, "n_gpus": 2, "backend": "gloo", "max_rank": 1}
+    # a failing rank must surface as a non-zero exit code of the parent
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch", "--config", "nope", "--bogus-flag"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert bad.returncode != 0

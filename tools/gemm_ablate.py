@@ -16,7 +16,7 @@ for (m, n, k) in [(M, D, 4 * D), (M, 3 * D, D), (M, D, D)]:
     res = {}
     for rnd in range(2):
         for name, v in (("full", 2), ("no_dma", 3), ("no_mfma", 4)):
-            hip.check(hip.lib().vt_set_gemm_variant(v))
+            hip.GEMM_TILE = v
             for _ in range(3):
                 hip.gemm_nt(A, B, hip.EPI_BF16, out=out)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,4 +27,4 @@ for (m, n, k) in [(M, D, 4 * D), (M, 3 * D, D), (M, D, D)]:
             torch.cuda.synchronize()
             res[name] = e0.elapsed_time(e1) / 20 * 1e3
     print(f"M={m} N={n} K={k}: " + "  ".join(f"{kk} {vv:.1f} us" for kk, vv in res.items()), flush=True)
-hip.check(hip.lib().vt_set_gemm_variant(0))
+hip.GEMM_TILE = 0

@@ -10,7 +10,7 @@ import video_tokenizer_amd.hip as hip  # noqa: E402
 
 
 def bench_nt(M, N, K, epi, variant, reps=20):
-    hip.check(hip.lib().vt_set_gemm_variant(variant))
+    hip.GEMM_TILE = variant
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     B = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
     kw = {}
@@ -37,7 +37,7 @@ def bench_nt(M, N, K, epi, variant, reps=20):
 
 
 def bench_tn(M, shapes, variant, reps=10):
-    hip.check(hip.lib().vt_set_gemm_variant(variant))
+    hip.GEMM_TILE = variant
     probs = []
     for P, Q in shapes:
         probs.append(dict(A=torch.randn(M, P, device="cuda").to(torch.bfloat16), B=torch.randn(M, Q, device="cuda").to(torch.bfloat16),
@@ -79,4 +79,4 @@ if __name__ == "__main__":
     wg4 = wg * 2
     us = bench_tn(M, wg4, 2)
     print(f"wgrad group (8 problems = 2 blocks) v2: {us:7.1f} us {2 * f / us / 1e6:7.1f} TF/s")
-    hip.check(hip.lib().vt_set_gemm_variant(0))
+    hip.GEMM_TILE = 0

@@ -21,7 +21,7 @@ def run(M, N, K, fill, reps=200):
         A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         B = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    hip.check(hip.lib().vt_set_gemm_variant(2))
+    hip.GEMM_TILE = 2
     for _ in range(5):
         hip.gemm_nt(A, B, hip.EPI_BF16, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -16,4 +16,4 @@ for M in (8200, 16400):
             us = bench_nt(M, n, k, epi, v, reps=40)
             row += f" | v{v}: {us:6.1f} us {2.0 * M * n * k / us / 1e6:6.1f} TF"
         print(row, flush=True)
-hip.check(hip.lib().vt_set_gemm_variant(0))
+hip.GEMM_TILE = 0

@@ -28,4 +28,4 @@ if __name__ == "__main__":
                     row += f" | v{v}: {us:6.1f} us {2.0 * m * n * k / us / 1e6:6.1f} TF"
         print(row, flush=True)
     print("sum per block: " + ", ".join(f"v{v} {tot[v]:.0f} us" for v in variants))
-    hip.check(hip.lib().vt_set_gemm_variant(0))
+    hip.GEMM_TILE = 0

@@ -19,4 +19,4 @@ for M in (4096, 8192):
         t128 = -(-M // 128) * -(-n // 128)
         row += f" | tiles192 {t192} tiles128 {t128}"
         print(row, flush=True)
-hip.check(hip.lib().vt_set_gemm_variant(0))
+hip.GEMM_TILE = 0

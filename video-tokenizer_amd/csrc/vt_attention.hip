@@ -25,6 +25,7 @@
 // transposed b64 reads (derivation in DESIGN.md).  The image is written lane-linearly by the LDS-DMA, so the
 // XOR goes on the per-lane source address.
 #include "vt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -108,6 +109,17 @@ __device__ __forceinline__ void load_own(const bf16_t* __restrict__ src, int64_t
 #pragma unroll
     for (int s = 0; s < KS; ++s) f[s] = *(const bf16x8*)(p + 16 * s);
 }
+
+// Own-row operands arrive by ordinary global loads that hipcc counts; the tile loops stage by inline-asm LDS-DMA that it
+// does not.  Left alone, hipcc places the wait for the own-row loads at their first use INSIDE the loop as vmcnt(3..0) --
+// which at run time drains the next tile's just-issued DMA at the top of every iteration (the prefetch never overlapped
+// the tile's compute).  Making the registers opaque here puts that wait in front of the loop, once.
+template <int N>
+__device__ __forceinline__ void pin_loaded(bf16x8 (&f)[N]) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) asm volatile("" : "+v"(f[s]));
+}
+__device__ __forceinline__ void pin_loaded(float& x) { asm volatile("" : "+v"(x)); }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int sp) {
     bf16x8 r;
@@ -234,6 +246,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
     stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
+    pin_loaded(qf);
     dma_drain();
     __syncthreads();
 
@@ -266,6 +279,319 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     const bool ok = q < L;
     store_own<DT>(oacc, 1.0f / ltot, o + (int64_t)b * Lq * H * HD + (int64_t)h * HD, (int64_t)H * HD, q - q_begin, ok, half);
     if (ok && half == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);  // v_log_f32 = log2
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, software-pipelined inside the wave (head_dim 64)
+//
+// The plain kernel above runs S = K.Q^T, the softmax and O += V^T.P one after the other, so a wave's matrix instructions
+// and its vector instructions never overlap (PMC, round 1: matrix pipe 27 % busy + vector issue 55 % of the kernel, the
+// SUM of the two was the run time; co-resident waves did not fill the gaps).  Here the unit of work is a 32-key HALF tile
+// and every iteration v issues, in program order,
+//     4 MFMAs  S(v+1) = K_half(v+1) . Q^T        (scores of the NEXT half)
+//     4 MFMAs  O^T   += V_half(v-1)^T . P(v-1)   (accumulate the PREVIOUS half)
+// with the 16 exponentials / row sums / bf16 packs of half v -- which depend on neither -- placed between them, two
+// elements per MFMA, in source order fenced by sched_barrier(0).  An MFMA keeps the SIMD's vector issue for 8 of its 32
+// cycles, so ~6 vector instructions ride in its shadow.
+//
+// LDS ring: K and V each two 64-key buffers.  Iteration 2t reads K(t) rows 32..63 and V(t-1) rows 32..63; iteration
+// 2t+1 reads K(t+1) rows 0..31 and V(t) rows 0..31, and issues the DMA of K(t+2) -> K buffer t&1 and V(t+1) -> V buffer
+// (t+1)&1, both last read in iteration 2t: ONE vmcnt(0) + barrier per 64 keys, after the even iteration.
+//
+// Lazy rescaling with a pipeline: the decision for half v+1 is taken at the end of iteration v (its scores are ready),
+// the new reference point is used for the exponentials of v+1, and O / l -- which by then also hold half v, exponentiated
+// at the OLD reference -- are multiplied by alpha at the end of iteration v+1 ("scale everything still at the old
+// reference exactly once").  A ragged last tile is not pipelined: fwd_tile<TAIL> after the loop.
+// ------------------------------------------------------------------------------------------------
+// max / sum of a value with its partner lane (lane ^ 32) without an index register or an LDS round trip:
+// v_permlane32_swap exchanges lanes 32..63 of the first operand with lanes 0..31 of the second
+__device__ __forceinline__ float xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+struct FwdState {
+    float m;          // reference point of the exponentials (log2 domain), per query = per lane
+    float lsum;       // row sum at the scale O is at
+    float alpha_p;    // pending multiplier for O / lsum
+    bool pend;        // wave-uniform
+};
+
+// Per-lane LDS byte offsets of the fragments, relative to a tile image: everything that depends on the buffer, the 32-row
+// half or the k-step is a compile-time constant added on top (the swizzle f(row) has period 8 rows), so it lands in the
+// instruction's offset field and the loop carries 8 address registers instead of ~50 hoisted address computations.
+struct PipeAddr {
+    unsigned k[4];       // K row fragment of k-step s: row lane&31
+    unsigned v[2][2];    // V transposed fragment, [dt][rows +0 / +8]
+};
+__device__ __forceinline__ PipeAddr pipe_addr(int lane) {
+    PipeAddr a;
+    const int row = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) a.k[s_] = row * 128 + (((2 * s_ + hf) ^ fsw<64>(row)) << 4);
+    const int g = lane >> 4, lam = lane & 15;
+    const int r0 = 4 * (g >> 1) + (lam >> 2), r1 = r0 + 8;
+    const int bo = (lam & 1) << 3;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int lc = ((dt * 32 + 16 * (g & 1)) >> 3) + ((lam & 3) >> 1);
+        a.v[dt][0] = r0 * 128 + ((lc ^ fsw<64>(r0)) << 4) + bo;
+        a.v[dt][1] = r1 * 128 + ((lc ^ fsw<64>(r1)) << 4) + bo;
+    }
+    return a;
+}
+constexpr int PIPE_TILE = 64 * 128;   // bytes of a [64][64] bf16 tile; LDS = [K0][V0][K1][V1]
+// `pa.k` point into the K buffer in use, `pa.v` into the V buffer in use (the buffer base is part of the register: the
+// kernel flips it with one XOR per address and tile); R0 = first row of the 32-row half, a compile-time constant
+template <int R0>
+__device__ __forceinline__ bf16x8 pipe_kfrag(const char* smem, const PipeAddr& pa, int s_) {
+    return *(const bf16x8*)(smem + pa.k[s_] + R0 * 128);
+}
+template <int R0>
+__device__ __forceinline__ bf16x8 pipe_vfrag(const char* smem, const PipeAddr& pa, int i) {   // i = 2 * sp + dt
+    const int sp = i >> 1, dt = i & 1;
+    const int cst = PIPE_TILE + (R0 + 16 * sp) * 128;
+    return cat4(lds_read_tr16(smem + pa.v[dt][0] + cst), lds_read_tr16(smem + pa.v[dt][1] + cst));
+}
+
+// one iteration: S_next = K rows [KR, KR+32) . Q^T (if QK), O += V rows [VR, VR+32) . p_prev (if PV), and the softmax of
+// s_cur -> p_cur (bf16 B fragments of the two 16-key k-steps), row sum into lsum
+// DBG (timing ablations, WRONG results; tools/attn_ablate.sh): 1 no exponentials, 2 no S MFMAs, 4 no PV MFMAs, 8 no LDS fragment
+// reads, 16 no softmax arithmetic at all
+template <bool QK, bool PV, int KR, int VR, int DBG = 0>
+__device__ __forceinline__ void fwd_pipe_iter(const char* smem, const PipeAddr& ad, const bf16x8 (&qf)[4], f32x16& s_next, f32x16& s_cur,
+                                              bf16x8 (&p)[2], f32x16 (&oacc)[2], FwdState& st, float c) {
+    // p: on entry the packed P of the previous half (B operands of the PV MFMAs), on exit those of this half.  Each k-step
+    // is re-packed right behind the last MFMA that reads the old one, so P never needs a second register set.
+    // Fragments are read two MFMAs ahead of their use into rotating registers.  hipcc is free to move pure arithmetic and
+    // MFMAs anywhere (it SINKS the softmax below the rescale branch and clusters the MFMAs when left alone), so the
+    // interleave is pinned by empty asm statements: PIN_F(frag) in front of an MFMA makes the MFMA wait for that point,
+    // PIN_P after a pair of exponentials keeps them above it; asm volatile statements keep their relative order.
+    bf16x8 fa, fb, fc, fd;
+#define VT_PIN_F(f) asm volatile("" : "+v"(f))
+    if (QK) { fa = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 0)); fb = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 1)); }
+    else if (PV) { fc = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 0)); fd = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 1)); }
+    // The kernel is bound by vector ISSUE (PMC: SQ_ACTIVE_INST_VALU 74 % of the kernel, one quad-cycle per plain VALU
+    // instruction and two per v_exp_f32, whatever the number of resident waves), so the arithmetic around the exponentials
+    // is done two elements per instruction: v_pk_fma_f32 for s * c - m, v_pk_add_f32 for the row sum.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 nm2 = {-st.m, -st.m}, c2 = {c, c};
+    f32x2 ps2 = {0.f, 0.f};
+#define VT_SM2(r)                                                            \
+    if (!(DBG & 16)) {                                                       \
+        const f32x2 sv = {s_cur[r], s_cur[(r) + 1]};                         \
+        const f32x2 t = __builtin_elementwise_fma(sv, c2, nm2);              \
+        f32x2 pv = {(DBG & 1) ? t[0] : __builtin_amdgcn_exp2f(t[0]), (DBG & 1) ? t[1] : __builtin_amdgcn_exp2f(t[1])}; \
+        ps2 += pv;                                                           \
+        asm volatile("" : "+v"(pv), "+v"(ps2));                              \
+        s_cur[r] = pv[0];                                                    \
+        s_cur[(r) + 1] = pv[1];                                              \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    }
+    if (QK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
+        VT_PIN_F(fa);
+        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qf[0], s_next, 0, 0, 0);
+        fa = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 2));
+    }
+    VT_SM2(0);
+    if (QK) {
+        VT_PIN_F(fb);
+        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, qf[1], s_next, 0, 0, 0);
+        fb = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 3));
+    }
+    VT_SM2(2);
+    if (QK) {
+        VT_PIN_F(fa);
+        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qf[2], s_next, 0, 0, 0);
+        if (PV) fc = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 0));
+    }
+    VT_SM2(4);
+    if (QK) {
+        VT_PIN_F(fb);
+        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, qf[3], s_next, 0, 0, 0);
+        if (PV) fd = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 1));
+    }
+    VT_SM2(6);
+    if (PV) {
+        VT_PIN_F(fc);
+        if (!(DBG & 4)) oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc, p[0], oacc[0], 0, 0, 0);
+        fc = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 2));
+    }
+    VT_SM2(8);
+    if (PV) {
+        VT_PIN_F(fd);
+        if (!(DBG & 4)) oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, p[0], oacc[1], 0, 0, 0);
+        fd = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 3));
+    }
+    p[0] = pack8(s_cur, 0);
+    VT_SM2(10);
+    if (PV) {
+        VT_PIN_F(fc);
+        if (!(DBG & 4)) oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc, p[1], oacc[0], 0, 0, 0);
+    }
+    VT_SM2(12);
+    if (PV) {
+        VT_PIN_F(fd);
+        if (!(DBG & 4)) oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, p[1], oacc[1], 0, 0, 0);
+    }
+    VT_SM2(14);
+    p[1] = pack8(s_cur, 1);
+#undef VT_SM2
+#undef VT_PIN_F
+    // O and lsum now hold half v-1 too: bring them to the reference the exponentials above used
+    if (st.pend) {
+        const float a = st.alpha_p;
+        st.lsum *= a;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= a;
+        st.pend = false;
+    }
+    st.lsum += ps2[0] + ps2[1];
+    if (QK) {   // decision for the half whose scores just arrived
+        float mx = fmaxf(s_next[0], s_next[1]);
+#pragma unroll
+        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s_next[r]);
+        mx = xhalf_max(mx);
+        const float want = mx * c;
+        if (__builtin_amdgcn_ballot_w64(want > st.m + 8.0f) != 0ull) {
+            const float mn = fmaxf(st.m, want);
+            st.alpha_p = __builtin_amdgcn_exp2f(st.m - mn);
+            st.m = mn;
+            st.pend = true;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the next iteration's reads / MFMAs stay behind this one (register pressure)
+}
+
+template <int DBG>
+__global__ __launch_bounds__(256, 4) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
+                                                                int L, int H, int nblk, float scale_log2e, int q_begin) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = sid / nblk, blk = sid - bh * nblk;
+    const int b = bh / H, h = bh % H;
+    const int64_t rs = (int64_t)3 * H * HD;
+    const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
+    const bf16_t* kb = qb + (int64_t)H * HD;
+    const bf16_t* vb = kb + (int64_t)H * HD;
+    const int q0 = q_begin + blk * 128 + wave * 32;
+    const int Lq = L - q_begin;
+
+    constexpr int TILE = AG<HD>::TILE;
+    static_assert(TILE == PIPE_TILE, "tile image size");
+    bf16x8 qf[4];
+    load_own<4>(qb, rs, q0, L, lane, qf);
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+
+    const int nt = (L + 63) / 64;
+    const int nfull = L / 64;                 // tiles the pipeline handles; a ragged last tile (nt == nfull + 1) runs after it
+    // LDS: [K buffer 0][V buffer 0][K buffer 1][V buffer 1]
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    unsigned soff[AG<HD>::CH / 4];
+    stage_offsets<HD>(rs, tid, soff);
+    // full tiles only inside the pipeline (scalar base + invariant lane offsets); the ragged last tile, if any, is staged
+    // with clamped rows after the loop -- its 64-bit per-lane address arithmetic would otherwise live in the hot loop
+    auto stage_k = [&](int t) { stage64_full<HD>(kb + (int64_t)t * 64 * rs, soff, sbase + (t & 1) * 2 * TILE, wave); };
+    auto stage_v = [&](int t) { stage64_full<HD>(vb + (int64_t)t * 64 * rs, soff, sbase + (t & 1) * 2 * TILE + TILE, wave); };
+    if (nfull > 0) {
+        stage_k(0);
+        stage_v(0);
+        if (nfull > 1) stage_k(1);
+    } else {
+        stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
+        stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
+    }
+    pin_loaded(qf);
+    dma_drain();
+    __syncthreads();
+
+    FwdState st;
+    st.m = -__builtin_inff();
+    st.lsum = 0.f;
+    st.alpha_p = 1.f;
+    st.pend = false;
+    const float c = scale_log2e;
+    if (nfull > 0) {
+        PipeAddr ad = pipe_addr(lane);      // K addresses -> K buffer 0, V addresses -> V buffer 0
+        f32x16 sa, sb;                      // scores of the current / next half (they swap roles every iteration)
+        bf16x8 pk[2];
+        {   // S(0) and its reference point
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pipe_kfrag<0>(smem, ad, s_), qf[s_], sa, 0, 0, 0);
+            float mx = fmaxf(sa[0], sa[1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sa[r]);
+            mx = xhalf_max(mx);
+            st.m = mx * c;
+        }
+        // iteration 0 (tile 0, second half of K): nothing to accumulate yet
+        fwd_pipe_iter<true, false, 32, 32, DBG>(smem, ad, qf, sb, sa, pk, oacc, st, c);
+        dma_drain();
+        __syncthreads();
+        // one trip per tile t: odd iteration 2t+1 (scores sb, previous P pa; K(t+1) rows 0.., V(t) rows 0..), then even
+        // iteration 2t+2 (scores sa, previous P pb; K(t+1) rows 32.., V(t) rows 32..).  K addresses point at buffer
+        // (t+1)&1, V addresses at buffer t&1: both flip at the end of the trip.
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) ad.k[s_] ^= 2 * PIPE_TILE;
+        for (int t = 0; t + 1 < nfull; ++t) {
+            if (t + 2 < nfull) stage_k(t + 2);
+            stage_v(t + 1);
+            fwd_pipe_iter<true, true, 0, 0, DBG>(smem, ad, qf, sa, sb, pk, oacc, st, c);
+            fwd_pipe_iter<true, true, 32, 32, DBG>(smem, ad, qf, sb, sa, pk, oacc, st, c);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) ad.k[s_] ^= 2 * PIPE_TILE;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                ad.v[dt][0] ^= 2 * PIPE_TILE;
+                ad.v[dt][1] ^= 2 * PIPE_TILE;
+            }
+            dma_drain();
+            __syncthreads();
+        }
+        {   // last full tile (t = nfull - 1): no further scores; accumulate both of its halves and leave the pipeline
+            if (nfull < nt) {   // the ragged tile: both of its buffers were last read before the loop's final barrier
+                stage64<HD>(kb, rs, nfull * 64, L, sbase + (nfull & 1) * 2 * TILE, tid, wave);
+                stage64<HD>(vb, rs, nfull * 64, L, sbase + (nfull & 1) * 2 * TILE + TILE, tid, wave);
+            }
+            fwd_pipe_iter<false, true, 0, 0, DBG>(smem, ad, qf, sa, sb, pk, oacc, st, c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                oacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pipe_vfrag<32>(smem, ad, i), pk[i >> 1], oacc[i & 1], 0, 0, 0);
+        }
+    }
+    float m = st.m, lsum = st.lsum;
+    // Everything the epilogue needs is recomputed from an opaque copy of the thread index: values kept live across the tile
+    // loop only for these few stores cost registers the loop has no room for (they were spilled to scratch otherwise).
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, half2 = lane2 >> 5;
+    if (nfull < nt) {
+        if (nfull > 0) {        // K(nfull) / V(nfull) were issued inside the loop (or the prologue): make them visible
+            dma_drain();
+            __syncthreads();
+        }
+        const char* kl = smem + (nfull & 1) * 2 * TILE;
+        fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane2, half2);
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32);
+    const int q = q_begin + blk * 128 + (tid2 >> 6) * 32 + (lane2 & 31);
+    const bool ok = q < L;
+    store_own<2>(oacc, 1.0f / ltot, o + (int64_t)b * Lq * H * HD + (int64_t)h * HD, (int64_t)H * HD, q - q_begin, ok, half2);
+    if (ok && half2 == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);
 }
 
 template <int HD, bool TAIL>
@@ -351,6 +677,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
     stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
+    pin_loaded(qf);
+    pin_loaded(dof);
+    float lse_pin = my_lse;
+    pin_loaded(lse_pin);
+    pin_loaded(my_delta);
     dma_drain();
     __syncthreads();
 
@@ -368,13 +699,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
             stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
         const char* kl = smem + cur * 2 * TILE;
-        dq_tile<HD, false>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, t * 64, L, scale_log2e, lane, half);
+        dq_tile<HD, false>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, t * 64, L, scale_log2e, lane, half);
         dma_drain();
         __syncthreads();
     }
     if (nfull < nt) {
         const char* kl = smem + (nfull & 1) * 2 * TILE;
-        dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, my_lse, my_delta, nfull * 64, L, scale_log2e, lane, half);
+        dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, nfull * 64, L, scale_log2e, lane, half);
     }
     store_own<DT>(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
 }
@@ -487,6 +818,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     };
     const int t0 = q_begin >> 6;
     stage(t0, 0);
+    pin_loaded(kf);
+    pin_loaded(vf);
     dma_drain();
     __syncthreads();
 
@@ -519,10 +852,32 @@ __global__ void zero_q_rows_kernel(bf16_t* __restrict__ dqkv, int L, int q_begin
 
 }  // namespace
 
+// A/B switch for tools/ (environment variable VT_ATTN_PLAIN=1 read once): the un-pipelined forward of round 1
+static const bool g_attn_plain_fwd = [] { const char* e = getenv("VT_ATTN_PLAIN"); return e && e[0] == '1'; }();
+static const int g_attn_dbg = [] { const char* e = getenv("VT_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing ablations (wrong results)
+
 template <int HD>
 static void launch_fwd(const void* qkv, int B, int L, int H, int q_begin, void* o, float* lse2, hipStream_t s) {
     const float sl2 = (HD == 64 ? 0.125f : 0.17677669529663688110f) * 1.44269504088896340736f;
     const int nblk = (L - q_begin + 127) / 128;
+    if constexpr (HD == 64) {
+        if (!g_attn_plain_fwd) {
+#define VT_LAUNCH_PIPE(D) hipLaunchKernelGGL(attn_fwd_pipe_kernel<D>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2, q_begin)
+            switch (g_attn_dbg) {
+                case 1: VT_LAUNCH_PIPE(1); break;
+                case 2: VT_LAUNCH_PIPE(2); break;
+                case 4: VT_LAUNCH_PIPE(4); break;
+                case 6: VT_LAUNCH_PIPE(6); break;
+                case 8: VT_LAUNCH_PIPE(8); break;
+                case 16: VT_LAUNCH_PIPE(16); break;
+                case 22: VT_LAUNCH_PIPE(22); break;
+                case 30: VT_LAUNCH_PIPE(30); break;
+                default: VT_LAUNCH_PIPE(0); break;
+            }
+#undef VT_LAUNCH_PIPE
+            return;
+        }
+    }
     hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2, q_begin);
 }
 

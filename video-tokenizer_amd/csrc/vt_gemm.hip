@@ -318,18 +318,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNArgs a) {
 int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half);
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s);
 int vt_gemm192_init();
-static int g_gemm_variant = 0;  // 0 auto, 1 force 128x128 tiles, 2 force 192x192 tiles, 5 force 192x96 tiles (two workgroups per CU)
-
-// test/tuning hook: choose the tile generation used by vt_gemm_nt / vt_gemm_tn_grouped
-extern "C" int vt_set_gemm_variant(int32_t v) {
-    VT_CHECK_ARG(v >= 0 && v <= 6, "vt_set_gemm_variant: 0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96 (NT only), 6 = 192x192 one tile per workgroup (NT only); 3/4: timing experiments, wrong results");
-    g_gemm_variant = v;
-    return VT_OK;
-}
-
 extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
+    const int g_gemm_variant = p.tile;   // per call (vtGemmNT.tile); the library holds no tile setting of its own
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 6, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup; 3/4 timing ablations)", g_gemm_variant);
     VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
@@ -399,6 +392,8 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     TNArgs a;
     a.n = n;
     a.tile_start[0] = 0;
+    const int g_gemm_variant = ph[0].tile;
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 6, "vt_gemm_tn_grouped: tile %d (0 auto, 1 = 128x128, 2 = 192x192)", g_gemm_variant);
     bool big = g_gemm_variant != 1 && (g_gemm_variant < 3 || g_gemm_variant >= 5);  // auto: 192x192 tiles when every problem of the group is at least one tile
     for (int g = 0; g < n; ++g) {
         const vtGemmTN& p = ph[g];

@@ -34,7 +34,7 @@ __device__ __forceinline__ void raw_barrier() {
 struct NT192Args {
     vtGemmNT p;
     int tiles_m, tiles_n;
-    int dbg;      // timing experiments only (vt_set_gemm_variant 3/4): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads
+    int dbg;      // timing experiments only (vtGemmNT.tile 3/4): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads
 };
 
 // Geometry of the two NT instantiations.  WN = waves along N (each wave owns 96 x 48 outputs):
@@ -43,7 +43,7 @@ struct NT192Args {
 //           gemm_half_bench.py): within 0-8 % BEHIND the 192x192 kernel on every training shape.  Co-resident
 //           workgroups start together and stay in phase (the dispatcher puts blocks b and b+256 on one CU,
 //           tools/probes/placement_probe.hip), so their epilogues do not fall into each other's main loops, and a
-//           forced start offset cost more than it recovered.  Kept as a tile option (vt_set_gemm_variant(5)) and as
+//           forced start offset cost more than it recovered.  Kept as a tile option (vtGemmNT.tile = 5) and as
 //           the record of that experiment; auto dispatch never picks it.
 template <int WN>
 struct NTGeo {

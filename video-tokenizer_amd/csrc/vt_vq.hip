@@ -81,8 +81,10 @@ __device__ __forceinline__ unsigned pcg_hash(unsigned v) {
 
 // Gumbel(0,1) noise from a counter-based hash of (seed, token, code): argmax(logit + G) is a draw from
 // softmax(logit) == torch.multinomial(softmax(.), 1)  (bottleneck.py:276-280), in one pass.
+// The per-call counter (seed_lo) is hashed on its own before the token index is added: with token ^ seed_lo the noise vector of
+// (token t, call s) was that of (t ^ s ^ s', call s'), i.e. every call re-used the same N noise vectors, permuted over tokens.
 __device__ __forceinline__ float gumbel(unsigned seed_lo, unsigned seed_hi, unsigned token, unsigned code) {
-    const unsigned h = pcg_hash(pcg_hash(token ^ seed_lo) + code * 0x9E3779B1u + seed_hi);
+    const unsigned h = pcg_hash(pcg_hash(pcg_hash(seed_lo) + token) + code * 0x9E3779B1u + seed_hi);
     const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
     return -__logf(-__logf(u));
 }

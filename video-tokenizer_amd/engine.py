@@ -299,11 +299,14 @@ class TokenizerFunction(torch.autograd.Function):
         lib = hip.lib()
         red = engine.reducer
         named = dict(engine.model.named_parameters())
-        # gradient accumulation: parameters whose .grad already IS a view of the flat buffer (no zero_grad(set_to_none=True)
-        # since the last step) keep their old values: save them, let the kernels overwrite, add back afterwards.
+        # Gradient accumulation: a parameter whose .grad already IS a view of the flat buffer (no zero_grad(set_to_none=True)
+        # since the last backward) would lose its accumulated value when the kernels overwrite the slot.  Save those slots,
+        # let the kernels write, then hand autograd the NEW gradient as a tensor of its own and put the old value back --
+        # AccumulateGrad adds in place (the slot ends as old + new), and torch.autograd.grad() gets a real tensor without
+        # .grad being touched.  Only aliased slots are copied; the common path (grads set to None each step) copies nothing.
         lo_ptr, hi_ptr = engine.flat_grad.data_ptr(), engine.flat_grad.data_ptr() + engine.flat_grad.numel() * 4
-        aliased = {n for n in engine.apply_names if named[n].grad is not None and lo_ptr <= named[n].grad.data_ptr() < hi_ptr}
-        saved = engine.flat_grad.clone() if aliased else None
+        aliased = [n for n in engine.apply_names if named[n].grad is not None and lo_ptr <= named[n].grad.data_ptr() < hi_ptr]
+        saved = {n: engine.grad_views[n].clone() for n in aliased}
         final = ctypes.c_int32(0)
         done = 0
         # without a reducer the whole backward is one enqueue; with one, stage by stage so finished slices can be reduced
@@ -317,15 +320,16 @@ class TokenizerFunction(torch.autograd.Function):
                 done += 1
         if red is not None:
             red.finish()
-        if saved is not None:
-            engine.flat_grad.add_(saved)
         grads = []
-        # autograd wants gradients in the order the parameters were passed to apply()
+        # autograd wants gradients in the order the parameters were passed to apply().  NOTE for callers: except in the aliased
+        # case these are views of ONE reused buffer -- the next backward of this model overwrites them.
         for name in engine.apply_names:
-            if not named[name].requires_grad or name in aliased:
-                grads.append(None)  # aliased: .grad already shows old + new through the flat buffer
-            elif saved is not None:
-                grads.append(engine.grad_views[name] - saved[engine.grad_offsets[name]:engine.grad_offsets[name] + named[name].numel()].view_as(named[name]))
+            if not named[name].requires_grad:
+                grads.append(None)
+            elif name in saved:
+                fresh = engine.grad_views[name].clone()
+                engine.grad_views[name].copy_(saved[name])
+                grads.append(fresh)
             else:
                 # a FRESH view object (use_count 1) so AccumulateGrad adopts it instead of cloning 694 MB per step
                 grads.append(engine.grad_views[name].view(named[name].shape))

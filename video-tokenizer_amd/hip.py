@@ -27,12 +27,18 @@ class GemmNT(ctypes.Structure):
     _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("epi", c_i32), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64), ("bias", c_vp),
                 ("residual", c_vp), ("ldr", c_i64), ("rowmod", c_vp), ("rowmod_period", c_i32), ("aux", c_vp),
-                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp)]
+                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp), ("tile", c_i32)]
 
 
 class GemmTN(ctypes.Structure):
     _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("P", c_i32), ("Q", c_i32),
-                ("out", c_vp), ("ldo", c_i64), ("p_lim", c_i32), ("q_lim", c_i32), ("row_perm", c_vp)]
+                ("out", c_vp), ("ldo", c_i64), ("p_lim", c_i32), ("q_lim", c_i32), ("row_perm", c_vp), ("tile", c_i32)]
+
+# Tile generation the gemm_nt / gemm_tn_grouped wrappers below put into vtGemmNT.tile / vtGemmTN.tile when the caller
+# passes none: 0 = the library's automatic choice.  Tests and tools set it to A/B the tile generations; it lives on the
+# Python side only (the C library has no setting of its own, the field travels with every call).
+GEMM_TILE = 0
+
 
 
 # every symbol include/vt_hip.h declares: name -> (restype, argtypes)
@@ -41,7 +47,6 @@ SIGNATURES = {
     "vt_last_error": (c_i32, [ctypes.c_char_p, c_sz]),
     "vt_gemm_nt": (c_i32, [ctypes.POINTER(GemmNT), c_vp]),
     "vt_gemm_tn_grouped": (c_i32, [ctypes.POINTER(GemmTN), c_i32, c_vp]),
-    "vt_set_gemm_variant": (c_i32, [c_i32]),
     "vt_layernorm_fwd": (c_i32, [c_vp, RowMap, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32]),
     "vt_layernorm_bwd": (c_i32, [c_vp, c_vp, RowMap, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -192,7 +197,7 @@ def stream():
 # ---------------------------------------------------------------------------------------------
 
 def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
-            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None):
+            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None):
     """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous)."""
     require_gpu(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
@@ -216,6 +221,7 @@ def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, r
     p.omap = omap if omap is not None else IDENT
     p.round_bf16 = int(round_bf16)
     p.colsum_partial = colsum_partial.data_ptr() if colsum_partial is not None else None
+    p.tile = GEMM_TILE if tile is None else tile
     check(lib().vt_gemm_nt(ctypes.byref(p), stream()), "vt_gemm_nt")
     return (out, out2) if epi == EPI_BF16_GELU else out
 
@@ -233,6 +239,7 @@ def gemm_tn_grouped(problems):
         g.q_lim = pr.get("q_lim", B.shape[1])
         rp = pr.get("row_perm")
         g.row_perm = rp.data_ptr() if rp is not None else None
+        g.tile = pr.get("tile", GEMM_TILE)
     check(lib().vt_gemm_tn_grouped(arr, len(problems), stream()), "vt_gemm_tn_grouped")
 
 

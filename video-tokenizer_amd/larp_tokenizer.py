@@ -227,9 +227,24 @@ class LARPTokenizer(nn.Module):
         o = {"indices": idx, "projected_z": pz, "input_norms": norms, "unregularized_z": uz, "emb": emb, "regularized_z": rz, "losses": losses}
         return {"pred_frames": pred, "encoded": encoded, **self._bottleneck_dict(o)}
 
-    @torch.no_grad()
+    def _warn_if_graph_expected(self, who, *tensors):
+        """encode / decode on their own are forward-only here (the reference's are ordinary differentiable methods,
+        larp_tokenizer.py:400-487): only forward(data) carries a backward.  Say so once instead of silently returning
+        graph-less tensors to a caller that is recording a graph."""
+        if torch.is_grad_enabled() and not getattr(self, "_warned_nograd", False) and (
+                any(t.requires_grad for t in tensors if torch.is_tensor(t)) or (self.training and any(p.requires_grad for p in self.parameters()))):
+            import warnings
+            self._warned_nograd = True
+            warnings.warn(f"LARPTokenizer.{who}: forward-only in this build (no autograd graph is recorded); back-propagate through "
+                          "model(data) instead.  Wrap the call in torch.no_grad() to silence this.", stacklevel=3)
+
     def encode(self, x):
         """larp_tokenizer.py:400-428 (vq branch), forward only."""
+        self._warn_if_graph_expected("encode", x)
+        with torch.no_grad():
+            return self._encode(x)
+
+    def _encode(self, x):
         _, _, o = _engine.run_encode(self._engine, x)
         return {"encoded": o["encoded"], **self._bottleneck_dict(o)}
 
@@ -241,9 +256,13 @@ class LARPTokenizer(nn.Module):
         out["num_x_tokens"] = (T // self.temporal_patch_size) * (S // self.patch_size) ** 2
         return out
 
-    @torch.no_grad()
     def decode(self, z, num_x_tokens=None):
-        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video."""
+        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video.  Forward only."""
+        self._warn_if_graph_expected("decode", z)
+        with torch.no_grad():
+            return self._decode(z, num_x_tokens)
+
+    def _decode(self, z, num_x_tokens=None):
         if not z.is_cuda:
             raise hip.HipError("LARPTokenizer.decode: input is on the CPU; no CPU fallback")
         eng = self._engine

@@ -56,6 +56,25 @@ class FusedAdam:
                 self.ema = flat.clone()
         return flat
 
+    def _active_runs(self, eng):
+        """Contiguous [lo, hi) element ranges of the flat buffers that torch.optim.Adam would update: parameters with
+        requires_grad and a gradient.  It skips the others entirely (no moment decay, no weight decay, no step) -- e.g. after
+        decoder_requires_grad_(False) / others_requires_grad_(False).  Also makes sure the flat gradient slot holds what
+        p.grad holds: autograd normally adopts the engine's view of the slot; if it made its own tensor, copy it back."""
+        runs, off = [], 0
+        for name, p, _ in _flat_order(self.model):
+            n = p.numel()
+            if p.requires_grad and p.grad is not None:
+                view = eng.grad_views[name]
+                if p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad.reshape(view.shape))
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = off + n
+                else:
+                    runs.append([off, off + n])
+            off += n
+        return runs, off
+
     @torch.no_grad()
     def step(self):
         flat = self._ensure()
@@ -63,15 +82,46 @@ class FusedAdam:
         if eng.flat_grad is None:
             raise hip.HipError("FusedAdam.step(): no gradients yet (run backward first)")
         g = eng.flat_grad
-        n = flat.numel()
-        assert g.numel() == n, "flat gradient and parameter buffers must have the same (padded) length"
+        assert g.numel() == flat.numel(), "flat gradient and parameter buffers must have the same (padded) length"
         grp = self.param_groups[0]
         self.step_count += 1
-        hip.check(hip.lib().vt_adam_step(hip.ptr(flat), hip.ptr(g), hip.ptr(self.m), hip.ptr(self.v), n, grp["lr"], grp["betas"][0],
-                                         grp["betas"][1], grp["eps"], grp["weight_decay"], self.step_count, hip.ptr(self.ema),
-                                         float(self.ema_decay or 0.0), hip.stream()), "vt_adam_step")
+        runs, total = self._active_runs(eng)
+        if runs and runs[-1][1] == total:
+            runs[-1][1] = flat.numel()          # the zero padding behind the last parameter rides along (n % 4 == 0)
+        lr, (b1, b2), eps, wd = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]
+        covered = 0
+        for lo, hi in runs:
+            # every parameter of this model has a multiple of 4 elements, so runs start and end on 16-byte boundaries; a
+            # model that breaks this gets the unaligned edge elements from the same formula in torch ops on the device
+            a, b = (lo + 3) // 4 * 4, hi // 4 * 4
+            for (x, y) in ((lo, min(a, hi)), (max(b, a), hi)):
+                if y > x:
+                    self._adam_slice_torch(flat, g, x, y, lr, b1, b2, eps, wd)
+            if b > a:
+                ema = self.ema[a:b] if self.ema is not None else None
+                hip.check(hip.lib().vt_adam_step(hip.ptr(flat[a:b]), hip.ptr(g[a:b]), hip.ptr(self.m[a:b]), hip.ptr(self.v[a:b]), b - a, lr, b1, b2,
+                                                 eps, wd, self.step_count, hip.ptr(ema), float(self.ema_decay or 0.0), hip.stream()), "vt_adam_step")
+            covered += hi - lo
+        if self.ema is not None and covered < flat.numel():
+            # update_ema (base_trainer.py:769-779) runs over EVERY parameter, frozen ones included: their EMA keeps relaxing
+            # towards the (unchanged) weight.  Frozen slices: ema = d * ema + (1 - d) * p, outside the fused launch.
+            d, prev = float(self.ema_decay), 0
+            for lo, hi in runs + [[flat.numel(), flat.numel()]]:
+                if lo > prev:
+                    self.ema[prev:lo].mul_(d).add_(flat[prev:lo], alpha=1.0 - d)
+                prev = hi
         eng.param_epoch = getattr(eng, "param_epoch", 0) + 1  # the kernel wrote the weights behind torch's version counters:
         #                                                          tell the engine to re-pack its bf16 operand copies
+
+    def _adam_slice_torch(self, flat, g, x, y, lr, b1, b2, eps, wd):
+        gg = g[x:y] + wd * flat[x:y]
+        self.m[x:y].mul_(b1).add_(gg, alpha=1.0 - b1)
+        self.v[x:y].mul_(b2).addcmul_(gg, gg, value=1.0 - b2)
+        bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        flat[x:y].sub_((lr / bc1) * self.m[x:y] / (self.v[x:y].sqrt() / bc2 ** 0.5 + eps))
+        if self.ema is not None:
+            d = float(self.ema_decay)
+            self.ema[x:y].mul_(d).add_(flat[x:y], alpha=1.0 - d)
 
     def zero_grad(self, set_to_none=True):
         for p in self.model.parameters():

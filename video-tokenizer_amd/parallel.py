@@ -27,6 +27,11 @@ class GradReducer:
         # RCCL averages inside the collective (ncclAvg): saves a read-modify-write pass over the 694 MB of gradients that
         # would compete with the backward kernels for HBM; gloo (CPU tests) has no AVG, so sum then scale there
         self.use_avg = dist.get_backend(process_group) == "nccl"
+        # inspection (tests / tools): with record_events set, every bucket's collective is bracketed by timing events on the
+        # comm stream and finish() records one on the compute stream behind the last backward kernel -> `events`
+        self.record_events = False
+        self.events = []      # [(start, stop)] per launched bucket of the last backward
+        self.compute_done = None
 
     def _launch(self, flat, lo, hi):
         if hi <= lo:
@@ -39,11 +44,17 @@ class GradReducer:
             ev.record(torch.cuda.current_stream(flat.device))  # slice fully written by kernels enqueued so far
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if self.record_events:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 if self.use_avg:
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
                 else:
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
                     view.mul_(1.0 / self.world)
+                if self.record_events:
+                    e1.record(self.comm_stream)
+                    self.events.append((e0, e1))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
             view.mul_(1.0 / self.world)
@@ -53,6 +64,7 @@ class GradReducer:
         """The slice flat[lo:hi] is final (kernels enqueued).  Slices arrive in increasing, contiguous order."""
         if self.pending is None:
             self.launched = []
+            self.events = []
             self.pending = (flat, lo, hi)
         else:
             f, plo, phi = self.pending
@@ -70,6 +82,9 @@ class GradReducer:
             self._launch(f, plo, phi)
             self.pending = None
             if f.is_cuda and self.comm_stream is not None:
+                if self.record_events:
+                    self.compute_done = torch.cuda.Event(enable_timing=True)
+                    self.compute_done.record(torch.cuda.current_stream(f.device))   # behind the last backward kernel
                 torch.cuda.current_stream(f.device).wait_stream(self.comm_stream)
 
 
