@@ -200,8 +200,9 @@ int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO
  * Backward: gscal = device {dL/dloss_q, dL/dloss_commit, dL/dloss_codebook} (may be NULL);
  * g_rz = dL/dregularized_z fp32 [N,ldg] (may be NULL); outputs dz_in (fp32 [N,d] and/or bf16
  * [N,ldp]) and the dense codebook gradient dW [K,d] (deterministic, no atomics: one-hot product on the exact
- * fp32 MFMA, cost independent of how the tokens spread over the codes).  `workspace`: vt_vq_workspace_bytes(N,K,d)
- * bytes, the forward's scratch may be reused.
+ * fp32 MFMA, cost independent of how the tokens spread over the codes); dW == NULL skips it (frozen codebook: the 'sq'
+ * quantizer `VectorQuantizer` of models/model_new/quantizer/fsq.py:144-230, K = 196 560, which is vt_vq_forward mode 1 with
+ * inv_tau = 1 and loss = d * loss_q).  `workspace`: vt_vq_workspace_bytes(N,K,d) bytes, the forward's scratch may be reused.
  * ------------------------------------------------------------------------------------------ */
 size_t vt_vq_workspace_bytes(int32_t N, int32_t K, int32_t d);
 int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
@@ -290,6 +291,8 @@ typedef struct {
     int32_t Nq, d, K;                     /* bottleneck_token_num, bottleneck_dim, codebook_size     */
     int32_t vq_mode, l2_normalized;       /* 0 l2-argmin | 1 cos-argmax | 2 cos-sample               */
     float inv_tau, beta, codebook_w;      /* 1/stochastic_temperature, commitment / codebook weights */
+    int32_t freeze_codebook;              /* 1: no codebook gradient is computed or written (bottleneck_type 'sq',
+                                             models/larp_tokenizer.py:225-229: frozen 196 560 x 24 codebook) */
 } vtTokenizerConfig;
 
 typedef struct {                          /* one timm Block; same struct (non-const use) for grads   */

@@ -205,6 +205,25 @@ def bottleneck_forward(x, p, prefix, mode="L", emu=False, **vq_kw):
             "input_norm_first": n_first, "input_norm_last": n_last, **reg}
 
 
+def sq_forward(z, emb_weight, beta=0.25, force_idx=None, chunk=2048):
+    """`VectorQuantizer.forward` of models/model_new/quantizer/fsq.py:170-207 with l2_norm=True, input_format='blc' -- the
+    'sq' bottleneck of LARPTokenizer (larp_tokenizer.py:225-229, 423-428): z / |z|, argmin(-z E^T) over the unit-normalised
+    codebook, z_q = normalize(E[idx]), loss = beta * mean_n sum_d (sg(z_q) - z)^2 + mean_n sum_d (z_q - sg(z))^2, output
+    z + sg(z_q - z).  PINNED by tests/golden/sq_*.npz (outputs of that class, loaded by file path).  The N x K product is taken
+    in row chunks (K = 196 560) -- same arithmetic per row."""
+    z = F.normalize(z.float(), dim=-1)
+    zf = z.reshape(-1, z.shape[-1])
+    emb = F.normalize(emb_weight, dim=-1)
+    if force_idx is None:
+        with torch.no_grad():
+            idx = torch.cat([torch.argmin(-zf[i:i + chunk] @ emb.t(), dim=1) for i in range(0, zf.shape[0], chunk)])
+    else:
+        idx = force_idx.reshape(-1).to(torch.int64)
+    zq = F.normalize(F.embedding(idx, emb_weight), dim=-1).view(z.shape)
+    loss = beta * torch.mean(((zq.detach() - z) ** 2).sum(dim=-1)) + torch.mean(((zq - z.detach()) ** 2).sum(dim=-1))
+    return {"output": z + (zq - z).detach(), "loss_codebook": loss, "indices": idx.reshape(z.shape[:-1]), "unregularized_z": z}
+
+
 def vq_decode(indices, emb_weight, l2_normalized=True):
     """bottleneck.py:327-344 get_codebook_entry."""
     zq = F.embedding(indices.reshape(-1), emb_weight)
@@ -250,9 +269,15 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
     tok = tok + p["encoder_patch_pe"]                                   # :407 (fp32 buffer)
     q_emb = p["encoder_latent_query_embed"].unsqueeze(0).repeat(b, 1, 1)  # :410
     z = encoder_parallel(tok, q_emb, p, "encoder.", cfg["encoder_depth"], cfg["encoder_num_heads"], emu)
-    bo = bottleneck_forward(z, p, "bottleneck.", mode, emu, **vq_kw)     # :420
-    encoded = bo.pop("output")
-    out = {"encoded": encoded, **bo}
+    if cfg.get("bottleneck_type", "vq") == "sq":                        # :423-428
+        zp = linear(z, p["sq_in_linear.weight"], p["sq_in_linear.bias"], emu)
+        sq = sq_forward(zp, p["bottleneck.embedding.weight"], force_idx=vq_kw.get("force_idx"))
+        encoded = linear(sq["output"], p["sq_out_linear.weight"], p["sq_out_linear.bias"], emu)
+        out = {"encoded": encoded, "loss_codebook": sq["loss_codebook"], "_indices": sq["indices"], "_projected_z": zp}
+    else:
+        bo = bottleneck_forward(z, p, "bottleneck.", mode, emu, **vq_kw)     # :420
+        encoded = bo.pop("output")
+        out = {"encoded": encoded, **bo}
     zz = encoded + p["decoder_latent_pe"]                               # :463-464
     dq = p["decoder_patch_query_embed"]
     if "decoder_patch_query_token_type_embed" in p:
@@ -312,11 +337,17 @@ def init_state_dict(cfg, seed=1234, zero_head=False, query_std=0.02):
             sd[pre + "mlp.fc1.bias"] = T(gen.uniform((4 * D,), nxt(), -0.02, 0.02))
             sd[pre + "mlp.fc2.weight"] = T(gen.xavier_uniform((D, 4 * D), nxt()))
             sd[pre + "mlp.fc2.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
-    sd["bottleneck.in_linear.weight"] = T(gen.xavier_uniform((d, D), nxt()))
-    sd["bottleneck.in_linear.bias"] = T(gen.uniform((d,), nxt(), -0.02, 0.02))
-    sd["bottleneck.out_linear.weight"] = T(gen.xavier_uniform((D, d), nxt()))
-    sd["bottleneck.out_linear.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
-    sd["bottleneck.regularizer.embedding.weight"] = T(gen.kaiming_uniform_codebook(K, d, nxt()))
+    if cfg.get("bottleneck_type", "vq") == "sq":   # larp_tokenizer.py:225-229; the codebook is INPUT DATA supplied by the caller (sd["bottleneck.embedding.weight"])
+        sd["sq_in_linear.weight"] = T(gen.xavier_uniform((24, D), nxt()))
+        sd["sq_in_linear.bias"] = T(gen.uniform((24,), nxt(), -0.02, 0.02))
+        sd["sq_out_linear.weight"] = T(gen.xavier_uniform((D, 24), nxt()))
+        sd["sq_out_linear.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
+    else:
+        sd["bottleneck.in_linear.weight"] = T(gen.xavier_uniform((d, D), nxt()))
+        sd["bottleneck.in_linear.bias"] = T(gen.uniform((d,), nxt(), -0.02, 0.02))
+        sd["bottleneck.out_linear.weight"] = T(gen.xavier_uniform((D, d), nxt()))
+        sd["bottleneck.out_linear.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
+        sd["bottleneck.regularizer.embedding.weight"] = T(gen.kaiming_uniform_codebook(K, d, nxt()))
     sd["final_layer.norm_final.weight"] = T(gen.uniform((D,), nxt(), 0.9, 1.1))
     sd["final_layer.norm_final.bias"] = T(gen.uniform((D,), nxt(), -0.05, 0.05))
     kp = pt * ps * ps * 3

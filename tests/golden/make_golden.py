@@ -200,6 +200,48 @@ def make_fsq(out):
         print(key, "codebook", q.codebook_size, "indices[:6]", info["indices"][:6].tolist())
 
 
+def sq_cases():
+    # (B, n), K, seed; K = 196560 uses the Leech shell (video-tokenizer_amd/sq.py::leech_minimal_vectors -- input data, regenerated by
+    # the tests), the others a hash-generated codebook
+    return [((2, 128), 4096, 601), ((1, 256), 196560, 602)]
+
+
+def sq_codebook(K, seed):
+    if K == 196560:
+        import video_tokenizer_amd as vt
+        return vt.sq.leech_minimal_vectors()
+    return gen.normal((K, 24), seed + 5)
+
+
+def make_sq(out):
+    """models/model_new/quantizer/fsq.py::VectorQuantizer (the 'sq' bottleneck, larp_tokenizer.py:225-229), loaded by file path;
+    predefined_codebook=None (the default path does not exist here), codebook copied in"""
+    fsq_mod = _load("ref_fsq", os.path.join(REF, "models/model_new/quantizer/fsq.py"))
+    for (b, n), K, seed in sq_cases():
+        W = sq_codebook(K, seed)
+        q = fsq_mod.VectorQuantizer(n_embed=K, embed_dim=24, l2_norm=True, beta=0.25, input_format="blc", predefined_codebook=None)
+        with torch.no_grad():
+            q.embedding.weight.copy_(torch.from_numpy(W))
+        z = torch.from_numpy(gen.normal((b, n, 24), seed + 1)).requires_grad_(True)
+        g = torch.from_numpy(gen.normal((b, n, 24), seed + 2))
+        o = q(z)
+        (o["output"] * g).sum().add(0.7 * o["loss_codebook"]).backward()
+        with torch.no_grad():
+            zn = torch.nn.functional.normalize(z.detach().reshape(-1, 24), dim=-1)
+            en = torch.nn.functional.normalize(torch.from_numpy(W), dim=-1)
+            cos = zn.double() @ en.double().t()
+            top2 = cos.topk(2, dim=-1)
+            idx = top2.indices[:, 0]
+        key = f"sq_N{b * n}_K{K}"
+        np.savez_compressed(os.path.join(out, key + ".npz"), idx=idx.numpy().astype(np.int32), margin=(top2.values[:, 0] - top2.values[:, 1]).numpy(),
+                            output=o["output"].detach().numpy(), loss_codebook=np.float32(o["loss_codebook"].item()), dz=z.grad.numpy(),
+                            keys=np.array(sorted(o.keys())), meta=np.array([b, n, K, seed], dtype=np.int64))
+        # the class returns no indices: the fp64 argmax above is checked against its output rows (z_q = output - z + z = codebook row)
+        zq = torch.nn.functional.normalize(torch.from_numpy(W)[idx], dim=-1).reshape(b, n, 24)
+        assert torch.allclose(o["output"].detach(), zq, atol=1e-6), "fp64 argmax disagrees with the reference's fp32 argmin"
+        print(key, "keys", sorted(o.keys()), "idx[:6]", idx[:6].tolist(), "min margin", float((top2.values[:, 0] - top2.values[:, 1]).min()))
+
+
 def make_rope(out):
     """models/model_new/base/rope.py (pure torch/einops): the 3-axis interleaved rotary table and its application"""
     rope = _load("ref_rope", os.path.join(REF, "models/model_new/base/rope.py"))
@@ -224,12 +266,13 @@ def make_rope(out):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("fsq", "rope"):  # only these fixtures (added after the others were committed)
-        {"fsq": make_fsq, "rope": make_rope}[sys.argv[1]](HERE)
+    if len(sys.argv) > 1 and sys.argv[1] in ("fsq", "rope", "sq"):  # only these fixtures (added after the others were committed)
+        {"fsq": make_fsq, "rope": make_rope, "sq": make_sq}[sys.argv[1]](HERE)
         sys.exit(0)
     models, bott, emb = load_reference()
     make_fsq(HERE)
     make_rope(HERE)
+    make_sq(HERE)
     make_vq(models, HERE)
     make_bottleneck(models, HERE)
     make_embed(emb, HERE)

@@ -74,7 +74,7 @@ def test_from_checkpoint_roundtrip_and_extra_keys(tmp_path):
 def test_unsupported_options_fail_loudly():
     cfg = O.make_cfg("tiny")
     s = spec_from_cfg(cfg)
-    s["args"]["bottleneck_type"] = "sq"
+    s["args"]["bottleneck_type"] = "fsq"
     with pytest.raises(NotImplementedError):
         vt.make(s)
     s = spec_from_cfg(cfg)
@@ -335,3 +335,27 @@ def test_product_geometry_table_and_synthetic_clips_equal_the_checkers():
     outside = src[:start] + src[end:]
     assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", outside, re.M)
     assert re.search(r"^\s*from oracle import", src[start:end], re.M)
+
+
+def test_sq_bottleneck_host_surface():
+    """LARPTokenizer(bottleneck_type='sq') (models/larp_tokenizer.py:225-229): parameter names and shapes of the reference's
+    state dict, the frozen 196 560 x 24 codebook, and the engine's parameter binding; no GPU needed to construct it."""
+    spec = vt.config.model_spec(vt.config.geometry("tiny"))
+    spec["args"]["bottleneck_type"] = "sq"
+    m = vt.make(spec)
+    sd = m.state_dict()
+    for k, shp in {"sq_in_linear.weight": (24, 768), "sq_in_linear.bias": (24,), "sq_out_linear.weight": (768, 24), "sq_out_linear.bias": (768,),
+                   "bottleneck.embedding.weight": (196560, 24)}.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert not any(k.startswith("bottleneck.in_linear") or "regularizer" in k for k in sd)
+    assert m.bottleneck.embedding.weight.requires_grad is False and m.sq_in_linear.weight.requires_grad
+    np.testing.assert_allclose(m.bottleneck.embedding.weight.norm(dim=-1).numpy(), 1.0, atol=1e-6)
+    assert m._vq_engine_cfg() == (1, True, 1.0, 0.25, 1.0, True)
+    from video_tokenizer_amd.engine import _flat_order
+    names = [n for n, _, _ in _flat_order(m)]
+    assert set(names) == {n for n, _ in m.named_parameters()} and len(names) == len(set(names))
+    with pytest.raises(NotImplementedError):
+        spec["args"]["bottleneck_type"] = "fsq"
+        vt.make(spec)
+    with pytest.raises(vt.hip.HipError):
+        m(torch.zeros(1, 3, 4, 32, 32))

@@ -255,3 +255,43 @@ def test_titok_oracle_fsq_restatement_matches_c_oracle_and_reference():
     z, _ = _fsq_inputs(levels, N, seed)
     codes, idx, bounded = T.fsq(torch.from_numpy(z), levels)
     assert np.array_equal(idx.numpy(), f["indices"]) and np.array_equal(codes.numpy(), f["codes"])
+
+
+# ------------------------------------------------------------------------------------------------ 'sq' quantizer
+def _sq_inputs(b, n, K, seed):
+    from tests.golden.make_golden import sq_codebook
+    return sq_codebook(K, seed), gen.normal((b, n, 24), seed + 1), gen.normal((b, n, 24), seed + 2)
+
+
+def test_leech_shell_generator():
+    """the generated codebook of the 'sq' bottleneck: 196 560 distinct unit vectors, closed under negation, inner products
+    in {0, +-1/4, +-1/2, +-1} (the kissing configuration of the Leech lattice), 759 octads behind it"""
+    import video_tokenizer_amd as vt
+    V = vt.sq.leech_minimal_vectors()
+    assert V.shape == (196560, 24) and V.dtype == np.float32
+    np.testing.assert_allclose((V.astype(np.float64) ** 2).sum(1), 1.0, atol=1e-6)
+    R = vt.sq.leech_minimal_vectors(normalized=False)
+    assert len(np.unique(R, axis=0)) == 196560 and len(np.unique(np.concatenate([R, -R]), axis=0)) == 196560
+    ip = R[::997].astype(np.int64) @ R.astype(np.int64).T
+    assert set(np.unique(ip).tolist()) <= {-32, -16, -8, 0, 8, 16, 32}
+    assert int((ip == 16).sum(1)[0]) == 4600        # every minimal vector has 4 600 neighbours at 60 degrees
+
+
+@pytest.mark.parametrize("case", [((2, 128), 4096, 601), ((1, 256), 196560, 602)])
+def test_sq_restatement_and_c_search_match_reference(case):
+    (b, n), K, seed = case
+    f = _load(f"sq_N{b * n}_K{K}")
+    assert [str(k) for k in f["keys"]] == ["loss_codebook", "output"]            # the reference's dict (fsq.py:206)
+    W, z, g = _sq_inputs(b, n, K, seed)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    o = O.sq_forward(zt, torch.from_numpy(W))
+    (o["output"] * torch.from_numpy(g)).sum().add(0.7 * o["loss_codebook"]).backward()
+    assert np.array_equal(o["indices"].reshape(-1).numpy().astype(np.int32), f["idx"])
+    np.testing.assert_allclose(o["output"].detach().numpy(), f["output"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(o["loss_codebook"].item(), f["loss_codebook"], rtol=1e-6)
+    np.testing.assert_allclose(zt.grad.numpy(), f["dz"], rtol=1e-5, atol=1e-7)
+    # fixed-order C search (what the HIP kernel implements): cosine argmax, first index
+    c = vq_c.vq_forward(z.reshape(-1, 24), W, "D", temperature=1.0)
+    mism = np.nonzero(c["idx"] != f["idx"].astype(np.int64))[0]
+    assert all(f["margin"][i] < 1e-6 for i in mism), (mism, f["margin"][mism])
+    np.testing.assert_allclose(24.0 * c["loss_q"], f["loss_codebook"], rtol=2e-6)   # loss = d * (beta + 1) * mean squared distance

@@ -606,7 +606,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             // VQ backward: straight-through + commitment to z, codebook loss to the embedding
             TRY(vt_vq_backward(WS(float, t->d_rz), 64, gscal, c.beta, c.codebook_w, WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(float, t->vq_E),
                                WS(float, t->vq_wnorm), WS(int64_t, t->vq_idx), t->Mq, c.K, c.d, c.l2_normalized, nullptr, WS(void, t->dz_pad), 64,
-                               G->codebook, WS(void, t->vq_ws), s));
+                               c.freeze_codebook ? nullptr : G->codebook, WS(void, t->vq_ws), s));
             // in_linear: bias grad, wgrad, dgrad scattered into the last Nq rows of the encoder output gradient
             TRY(vt_colsum(WS(void, t->dz_pad), 1, 64, id, t->Mq, 64, WS(float, t->tmp_vec), WS(void, t->cs_ws), s));
             TRY(copy_d2d(G->in_b, WS(void, t->tmp_vec), (size_t)c.d * 4, hs));

@@ -412,7 +412,7 @@ extern "C" size_t vt_vq_workspace_bytes(int32_t N, int32_t K, int32_t d) {
     int S, cps;
     vq_split_plan(N, Kp, &S, &cps);
     size_t f = (size_t)d * Kp + Kp + N + 2 * (size_t)S * N + (N + 255) / 256 + 64;
-    const size_t bwd = (size_t)cb_slabs(N) * K * d;  // slab partials of the codebook gradient (vt_vq_backward)
+    const size_t bwd = (size_t)cb_slabs(N) * K * d;  // slab partials of the codebook gradient (vt_vq_backward with dW != NULL)
     return (f > bwd ? f : bwd) * 4;
 }
 
@@ -485,10 +485,14 @@ extern "C" int vt_vq_backward(const float* g_rz, int64_t ldg, const float* gscal
                               const float* znorm, const float* E, const float* wnorm, const int64_t* idx, int32_t N, int32_t K,
                               int32_t d, int32_t l2_normalized, float* dz_in, void* dz_pad_bf16, int64_t ldp, float* dW,
                               void* workspace, vtStream stream) {
-    VT_CHECK_ARG(zn && znorm && E && wnorm && idx && (dz_in || dz_pad_bf16) && dW && workspace, "vt_vq_backward: null pointer");
+    VT_CHECK_ARG(zn && znorm && E && wnorm && idx && (dz_in || dz_pad_bf16) && workspace, "vt_vq_backward: null pointer");
     VT_CHECK_ARG(N > 0 && K > 0 && (d == 8 || d == 16 || d == 24 || d == 32), "vt_vq_backward: d=%d must be 8,16,24 or 32", d);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(vq_bwd_tokens_kernel, dim3((N + 255) / 256), dim3(256), 0, s, g_rz, ldg, gscal, beta, codebook_w, zn, znorm, E, idx, N, d, l2_normalized, dz_in, (bf16_t*)dz_pad_bf16, ldp);
+    if (!dW) {   // frozen codebook (the 'sq' quantizer, model_new/quantizer/fsq.py:165-167): no codebook gradient, 2NKd flops saved
+        VT_CHECK_LAUNCH("vt_vq_backward");
+        return VT_OK;
+    }
     const int ns = cb_slabs(N);
     const int slab_len = round_up((N + ns - 1) / ns, CB_CHUNK);
     float* part = (float*)workspace;

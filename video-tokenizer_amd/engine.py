@@ -43,12 +43,11 @@ def _flat_order(model):
         if i > 0:
             fc2b("decoder", i - 1, st)
     st = dd + 1
-    bt = model.bottleneck
     if model.use_decoder_patch_query_token_type_embed:
         out.append(("decoder_patch_query_token_type_embed", model.decoder_patch_query_token_type_embed, st))
-    out += [("bottleneck.out_linear.bias", bt.out_linear.bias, st), ("bottleneck.out_linear.weight", bt.out_linear.weight, st),
-            ("bottleneck.regularizer.embedding.weight", bt.regularizer.embedding.weight, st),
-            ("bottleneck.in_linear.bias", bt.in_linear.bias, st), ("bottleneck.in_linear.weight", bt.in_linear.weight, st)]
+    named = dict(model.named_parameters())
+    bn = model._bt_names   # 'vq': bottleneck.{in,out}_linear.* + bottleneck.regularizer.embedding.weight; 'sq': sq_{in,out}_linear.* + bottleneck.embedding.weight
+    out += [(bn[k], named[bn[k]], st) for k in ("out_b", "out_w", "codebook", "in_b", "in_w")]
     fc2b("encoder", de - 1, st)
     for k in range(1, de + 1):
         i = de - k
@@ -82,9 +81,10 @@ class _Tensors:
         t.dec_latent_pe = get("decoder_latent_pe")
         t.dec_patch_query = get("decoder_patch_query_embed")
         t.dec_token_type = get("decoder_patch_query_token_type_embed")
-        t.in_w, t.in_b = get("bottleneck.in_linear.weight"), get("bottleneck.in_linear.bias")
-        t.out_w, t.out_b = get("bottleneck.out_linear.weight"), get("bottleneck.out_linear.bias")
-        t.codebook = get("bottleneck.regularizer.embedding.weight")
+        bn = model._bt_names
+        t.in_w, t.in_b = get(bn["in_w"]), get(bn["in_b"])
+        t.out_w, t.out_b = get(bn["out_w"]), get(bn["out_b"])
+        t.codebook = get(bn["codebook"])
         t.head_norm_w, t.head_norm_b = get("final_layer.norm_final.weight"), get("final_layer.norm_final.bias")
         t.head_w, t.head_b = get("final_layer.linear.weight"), get("final_layer.linear.bias")
         t.enc_blocks = ctypes.cast(self.enc, ctypes.POINTER(hip.BlockTensors))
@@ -189,17 +189,17 @@ class TokenizerEngine:
     # ------------------------------------------------------------------ states
     def state_for(self, B, T, S, device):
         m = self.model
-        vq = m.bottleneck.regularizer
-        mode = vq.index_mode()
-        key = (B, T, S, mode, vq.inv_tau(), str(device))
+        mode, l2n, inv_tau, beta, cw, frozen = m._vq_engine_cfg()
+        key = (B, T, S, mode, inv_tau, str(device))
         st = self.states.get(key)
         if st is None:
             c = hip.TokenizerConfig()
             c.B, c.C, c.T, c.S, c.pt, c.p = B, m.in_channels, T, S, m.temporal_patch_size, m.patch_size
             c.D, c.H, c.depth_enc, c.depth_dec = m.encoder_hidden_size, m.encoder_num_heads, m.encoder.depth, m.decoder.depth
             c.Nq, c.d, c.K = m.bottleneck_token_num, m.bottleneck_dim, m.codebook_size
-            c.vq_mode, c.l2_normalized = mode, int(vq.l2_normalized)
-            c.inv_tau, c.beta, c.codebook_w = vq.inv_tau(), vq.beta, vq.codebook_loss_weight
+            c.vq_mode, c.l2_normalized = mode, int(l2n)
+            c.inv_tau, c.beta, c.codebook_w = inv_tau, beta, cw
+            c.freeze_codebook = int(frozen)
             st = _State(self, key, c, device)
             self.states[key] = st
         return st

@@ -236,7 +236,7 @@ class VectorQuantize(torch.autograd.Function):
         dev = o["zn"].device
         gs = torch.stack([t if t is not None else torch.zeros((), device=dev) for t in (g_q, g_c, g_cb)]).float().contiguous()
         g2 = g_rz.reshape(o["zn"].shape).float().contiguous() if g_rz is not None else None
-        dz, _, dW = hip.vq_backward(g2, gs, o, beta=beta, codebook_w=cw, l2_normalized=l2n)
+        dz, _, dW = hip.vq_backward(g2, gs, o, beta=beta, codebook_w=cw, l2_normalized=l2n, need_dW=ctx.needs_input_grad[1])
         return dz.reshape(ctx.shp), dW, None, None, None, None, None, None
 
 

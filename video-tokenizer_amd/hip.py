@@ -88,7 +88,7 @@ SIGNATURES = {
 
 class TokenizerConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("B", "C", "T", "S", "pt", "p", "D", "H", "depth_enc", "depth_dec", "Nq", "d", "K", "vq_mode", "l2_normalized")] + \
-               [(n, c_f32) for n in ("inv_tau", "beta", "codebook_w")]
+               [(n, c_f32) for n in ("inv_tau", "beta", "codebook_w")] + [("freeze_codebook", c_i32)]
 
 
 BLOCK_FIELDS = ("norm1_w", "norm1_b", "qkv_w", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
@@ -361,15 +361,15 @@ def vq_forward(z_in, codebook, mode, l2_normalized=True, inv_tau=1.0, beta=0.25,
     return o
 
 
-def vq_backward(g_rz, gscal, saved, beta=0.25, codebook_w=1.0, l2_normalized=True, ldp=0):
+def vq_backward(g_rz, gscal, saved, beta=0.25, codebook_w=1.0, l2_normalized=True, ldp=0, need_dW=True):
     zn, E = saved["zn"], saved["E"]
     N, d = zn.shape
     K = E.shape[0]
     dev = zn.device
     dz = torch.empty(N, d, device=dev)
     dz_pad = torch.zeros(N, ldp, device=dev, dtype=torch.bfloat16) if ldp else None
-    dW = torch.empty(K, d, device=dev)
-    ws = _ws(lib().vt_vq_workspace_bytes(N, K, d), dev)
+    dW = torch.empty(K, d, device=dev) if need_dW else None          # frozen codebook: the dense K x d gradient is skipped
+    ws = _ws(lib().vt_vq_workspace_bytes(N, K, d) if need_dW else 64, dev)
     check(lib().vt_vq_backward(ptr(g_rz), g_rz.stride(0) if g_rz is not None else 0, ptr(gscal), beta, codebook_w, ptr(zn),
                                ptr(saved["znorm"]), ptr(E), ptr(saved["wnorm"]), ptr(saved["idx"]), N, K, d, int(l2_normalized),
                                ptr(dz), ptr(dz_pad), ldp, ptr(dW), ptr(ws), stream()), "vt_vq_backward")

@@ -45,8 +45,8 @@ class LARPTokenizer(nn.Module):
                  use_decoder_patch_query_token_type_embed=False, encoder_query_gaussian_init=True, **ignored):
         super().__init__()
         # `ignored`: yaml keys the reference class does not take (e.g. use_pe, cfgs/larp_tokenizer.yaml:75)
-        if bottleneck_type != "vq":
-            raise NotImplementedError(f"bottleneck_type='{bottleneck_type}': this build implements the 'vq' bottleneck "
+        if bottleneck_type not in ("vq", "sq"):
+            raise NotImplementedError(f"bottleneck_type='{bottleneck_type}': this build implements the 'vq' and 'sq' bottlenecks "
                                       "(pass model.args.bottleneck_type vq); 'auto' builds no bottleneck in the reference either")
         if train_type != "simple":
             raise NotImplementedError("train_type 'mrope' is out of scope")
@@ -119,10 +119,26 @@ class LARPTokenizer(nn.Module):
         self.encoder = registry.make(enc_args)
         self.decoder = registry.make(dec_args)
 
-        self.bottleneck_dim = bottleneck["args"]["bottleneck_dim"]
-        self.bottleneck = registry.make(bottleneck, args={"token_nums": self.bottleneck_token_num, "input_dim": encoder_hidden_size,
-                                                          "output_dim": decoder_hidden_size})
-        self.codebook_size = bottleneck["args"]["regularizer"]["args"]["codebook_size"]
+        if bottleneck_type == "vq":
+            self.bottleneck_dim = bottleneck["args"]["bottleneck_dim"]
+            self.bottleneck = registry.make(bottleneck, args={"token_nums": self.bottleneck_token_num, "input_dim": encoder_hidden_size,
+                                                              "output_dim": decoder_hidden_size})
+            self.codebook_size = bottleneck["args"]["regularizer"]["args"]["codebook_size"]
+            # parameter names the fused engine binds (engine.py): in/out projection, codebook
+            self._bt_names = {"in_w": "bottleneck.in_linear.weight", "in_b": "bottleneck.in_linear.bias", "out_w": "bottleneck.out_linear.weight",
+                              "out_b": "bottleneck.out_linear.bias", "codebook": "bottleneck.regularizer.embedding.weight"}
+        else:
+            # larp_tokenizer.py:225-229: Linear(768, 24) -> VectorQuantizer(196 560 x 24, frozen, cosine) -> Linear(24, 768).  The yaml's
+            # `bottleneck` entry is ignored on this branch, as in the reference.  `sq_codebook` (extra keyword of this build): a .npy
+            # path or an array; default = the reference's default path, replaced by the generated Leech shell when the file is absent.
+            from .sq import VectorQuantizer
+            self.sq_in_linear = nn.Linear(encoder_hidden_size, 24)
+            self.sq_out_linear = nn.Linear(24, decoder_hidden_size)
+            cb = ignored.get("sq_codebook", "/data2/zhxie/myproject/bsq-vit/cache/leech_lattices_normalized.npy")
+            self.bottleneck = VectorQuantizer(n_embed=196_560, embed_dim=24, l2_norm=True, beta=0.25, input_format="blc", predefined_codebook=cb)
+            self.bottleneck_dim, self.codebook_size = 24, 196_560
+            self._bt_names = {"in_w": "sq_in_linear.weight", "in_b": "sq_in_linear.bias", "out_w": "sq_out_linear.weight",
+                              "out_b": "sq_out_linear.bias", "codebook": "bottleneck.embedding.weight"}
         self.final_layer = OutputLayer(decoder_hidden_size, decoder_temporal_patch_size, decoder_patch_size, self.out_channels)
         self.prior_model = None  # the reference never builds one (larp_tokenizer.py:239-241); the trainer reads the attribute
         self.initialize_weights()
@@ -163,7 +179,16 @@ class LARPTokenizer(nn.Module):
         return self.final_layer.linear.weight
 
     def set_vq_eval_deterministic(self, deterministic=True):
-        self.bottleneck.regularizer.set_eval_deterministic(deterministic)
+        if self.bottleneck_type == "vq":
+            self.bottleneck.regularizer.set_eval_deterministic(deterministic)
+
+    def _vq_engine_cfg(self):
+        """(index mode, l2_normalized, 1/tau, beta, codebook weight, frozen codebook) for the fused engine"""
+        if self.bottleneck_type == "vq":
+            vq = self.bottleneck.regularizer
+            return vq.index_mode(), bool(vq.l2_normalized), vq.inv_tau(), float(vq.beta), float(vq.codebook_loss_weight), False
+        # 'sq': argmin(-z E^T) == first argmax of the cosine in every mode (model_new/quantizer/fsq.py:176-183), frozen codebook
+        return 1, True, 1.0, float(self.bottleneck.beta), 1.0, True
 
     @property
     def device(self):
@@ -210,6 +235,10 @@ class LARPTokenizer(nn.Module):
 
     # ------------------------------------------------------------------------------- hot path
     def _bottleneck_dict(self, o):
+        if self.bottleneck_type == "sq":
+            # fsq.py:195-206: loss = beta * mean_n sum_d (sg(q) - z)^2 + mean_n sum_d (q - sg(z))^2 = d * (engine loss_q); only key besides
+            # 'encoded' (larp_tokenizer.py:423-428)
+            return {"loss_codebook": o["losses"][0] * float(self.bottleneck_dim)}
         zero = torch.zeros((), device=o["losses"].device)
         return {
             "bottleneck_rep": o["indices"], "projected_z": o["projected_z"],
@@ -225,6 +254,8 @@ class LARPTokenizer(nn.Module):
         trainers/larp_tokenizer_trainer.py:294-333,372)."""
         pred, losses, encoded, idx, pz, uz, rz, emb, norms = _engine.apply(self._engine, data)
         o = {"indices": idx, "projected_z": pz, "input_norms": norms, "unregularized_z": uz, "emb": emb, "regularized_z": rz, "losses": losses}
+        if self.bottleneck_type == "sq":
+            self.last_indices = idx     # the reference's 'sq' dict carries no token ids (fsq.py:206); kept here for inspection / tests
         return {"pred_frames": pred, "encoded": encoded, **self._bottleneck_dict(o)}
 
     def _warn_if_graph_expected(self, who, *tensors):
@@ -282,7 +313,8 @@ class LARPTokenizer(nn.Module):
 
     @torch.no_grad()
     def decode_from_bottleneck(self, bottleneck_rep):
-        """larp_tokenizer.py:484-487: indices (b, Nq) -> bottleneck.decode -> decode."""
+        """larp_tokenizer.py:484-487: indices (b, Nq) -> bottleneck.decode -> decode.  ('sq': the reference's VectorQuantizer has
+        no .decode and fails there with AttributeError; here the same entry point works -- codebook row -> sq_out_linear.)"""
         import ctypes
         if not bottleneck_rep.is_cuda:
             raise hip.HipError("LARPTokenizer.decode_from_bottleneck: input is on the CPU; no CPU fallback")
