@@ -467,8 +467,9 @@ __device__ __forceinline__ void fwd_pipe_iter(const char* smem, const PipeAddr& 
     __builtin_amdgcn_sched_barrier(0);   // the next iteration's reads / MFMAs stay behind this one (register pressure)
 }
 
-template <int DBG>
-__global__ __launch_bounds__(256, 4) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
+// NW waves per workgroup (4 or 8), 32 queries each: 8 waves share one K/V stream, which halves the L2 -> LDS traffic per query
+template <int DBG, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
                                                                 int L, int H, int nblk, float scale_log2e, int q_begin) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_pipe_kernel(const bf16_t* __r
     const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
     const bf16_t* kb = qb + (int64_t)H * HD;
     const bf16_t* vb = kb + (int64_t)H * HD;
-    const int q0 = q_begin + blk * 128 + wave * 32;
+    const int q0 = q_begin + blk * (32 * NW) + wave * 32;
     const int Lq = L - q_begin;
 
     constexpr int TILE = AG<HD>::TILE;
@@ -499,19 +500,37 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_pipe_kernel(const bf16_t* __r
     const int nfull = L / 64;                 // tiles the pipeline handles; a ragged last tile (nt == nfull + 1) runs after it
     // LDS: [K buffer 0][V buffer 0][K buffer 1][V buffer 1]
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    unsigned soff[AG<HD>::CH / 4];
-    stage_offsets<HD>(rs, tid, soff);
+    constexpr int NTH = 64 * NW, PIECES = 512 / NTH;   // 16-B DMA pieces per thread and tile
+    unsigned soff[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int slot = i * NTH + tid, row = slot >> 3;
+        soff[i] = (unsigned)((row * rs + (((slot & 7) ^ fsw<HD>(row)) << 3)) * 2);
+    }
+    auto stage_full = [&](const bf16_t* tile_row0, unsigned lds) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) glds16_sv(tile_row0, soff[i], lds + (i * NTH + wave * 64) * 16);
+    };
+    auto stage_clamped = [&](const bf16_t* src, int row0, unsigned lds) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int slot = i * NTH + tid, row = slot >> 3;
+            int gr = row0 + row;
+            gr = gr < L ? gr : L - 1;
+            glds16_asm(src + (int64_t)gr * rs + (((slot & 7) ^ fsw<HD>(row)) << 3), lds + (i * NTH + wave * 64) * 16);
+        }
+    };
     // full tiles only inside the pipeline (scalar base + invariant lane offsets); the ragged last tile, if any, is staged
     // with clamped rows after the loop -- its 64-bit per-lane address arithmetic would otherwise live in the hot loop
-    auto stage_k = [&](int t) { stage64_full<HD>(kb + (int64_t)t * 64 * rs, soff, sbase + (t & 1) * 2 * TILE, wave); };
-    auto stage_v = [&](int t) { stage64_full<HD>(vb + (int64_t)t * 64 * rs, soff, sbase + (t & 1) * 2 * TILE + TILE, wave); };
+    auto stage_k = [&](int t) { stage_full(kb + (int64_t)t * 64 * rs, sbase + (t & 1) * 2 * TILE); };
+    auto stage_v = [&](int t) { stage_full(vb + (int64_t)t * 64 * rs, sbase + (t & 1) * 2 * TILE + TILE); };
     if (nfull > 0) {
         stage_k(0);
         stage_v(0);
         if (nfull > 1) stage_k(1);
     } else {
-        stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
-        stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
+        stage_clamped(kb, 0, sbase);
+        stage_clamped(vb, 0, sbase + TILE);
     }
     pin_loaded(qf);
     dma_drain();
@@ -564,8 +583,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_pipe_kernel(const bf16_t* __r
         }
         {   // last full tile (t = nfull - 1): no further scores; accumulate both of its halves and leave the pipeline
             if (nfull < nt) {   // the ragged tile: both of its buffers were last read before the loop's final barrier
-                stage64<HD>(kb, rs, nfull * 64, L, sbase + (nfull & 1) * 2 * TILE, tid, wave);
-                stage64<HD>(vb, rs, nfull * 64, L, sbase + (nfull & 1) * 2 * TILE + TILE, tid, wave);
+                stage_clamped(kb, nfull * 64, sbase + (nfull & 1) * 2 * TILE);
+                stage_clamped(vb, nfull * 64, sbase + (nfull & 1) * 2 * TILE + TILE);
             }
             fwd_pipe_iter<false, true, 0, 0, DBG>(smem, ad, qf, sa, sb, pk, oacc, st, c);
 #pragma unroll
@@ -588,7 +607,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_pipe_kernel(const bf16_t* __r
         fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane2, half2);
     }
     const float ltot = lsum + __shfl_xor(lsum, 32);
-    const int q = q_begin + blk * 128 + (tid2 >> 6) * 32 + (lane2 & 31);
+    const int q = q_begin + blk * (32 * NW) + (tid2 >> 6) * 32 + (lane2 & 31);
     const bool ok = q < L;
     store_own<2>(oacc, 1.0f / ltot, o + (int64_t)b * Lq * H * HD + (int64_t)h * HD, (int64_t)H * HD, q - q_begin, ok, half2);
     if (ok && half2 == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);
@@ -852,8 +871,12 @@ __global__ void zero_q_rows_kernel(bf16_t* __restrict__ dqkv, int L, int q_begin
 
 }  // namespace
 
-// A/B switch for tools/ (environment variable VT_ATTN_PLAIN=1 read once): the un-pipelined forward of round 1
-static const bool g_attn_plain_fwd = [] { const char* e = getenv("VT_ATTN_PLAIN"); return e && e[0] == '1'; }();
+// Experiment switch for tools/ (environment, read once).  VT_ATTN_PIPE=1 selects the software-pipelined forward below instead of
+// the plain one.  Measured (tools/ab_attn.sh, tools/attn_ablate.sh, profiles/r02_attention_*): the pipelined kernel issues its MFMAs
+// and exponentials perfectly interleaved and runs within +-3 % of the plain kernel on every box (84.6 vs 81.7 us, 86.6 vs 89.5 us),
+// 8 waves per workgroup (half the K/V staging traffic) is 10 % slower, so the plain kernel stays the default.
+static const bool g_attn_plain_fwd = [] { const char* e = getenv("VT_ATTN_PIPE"); return !(e && e[0] == '1'); }();
+static const int g_attn_waves = [] { const char* e = getenv("VT_ATTN_WAVES"); return e ? atoi(e) : 4; }();   // waves per workgroup of the pipelined forward
 static const int g_attn_dbg = [] { const char* e = getenv("VT_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing ablations (wrong results)
 
 template <int HD>
@@ -862,18 +885,18 @@ static void launch_fwd(const void* qkv, int B, int L, int H, int q_begin, void* 
     const int nblk = (L - q_begin + 127) / 128;
     if constexpr (HD == 64) {
         if (!g_attn_plain_fwd) {
-#define VT_LAUNCH_PIPE(D) hipLaunchKernelGGL(attn_fwd_pipe_kernel<D>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2, q_begin)
+            const int nw = g_attn_waves == 4 ? 4 : 8;
+            const int nb = (L - q_begin + 32 * nw - 1) / (32 * nw);
+#define VT_LAUNCH_PIPE(D, W) hipLaunchKernelGGL((attn_fwd_pipe_kernel<D, W>), dim3(nb * B * H), dim3(64 * W), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nb, sl2, q_begin)
+#define VT_LAUNCH_PIPE_W(D) if (nw == 4) VT_LAUNCH_PIPE(D, 4); else VT_LAUNCH_PIPE(D, 8)
             switch (g_attn_dbg) {
-                case 1: VT_LAUNCH_PIPE(1); break;
-                case 2: VT_LAUNCH_PIPE(2); break;
-                case 4: VT_LAUNCH_PIPE(4); break;
-                case 6: VT_LAUNCH_PIPE(6); break;
-                case 8: VT_LAUNCH_PIPE(8); break;
-                case 16: VT_LAUNCH_PIPE(16); break;
-                case 22: VT_LAUNCH_PIPE(22); break;
-                case 30: VT_LAUNCH_PIPE(30); break;
-                default: VT_LAUNCH_PIPE(0); break;
+                case 1: VT_LAUNCH_PIPE_W(1); break;
+                case 4: VT_LAUNCH_PIPE_W(4); break;
+                case 16: VT_LAUNCH_PIPE_W(16); break;
+                case 30: VT_LAUNCH_PIPE_W(30); break;
+                default: VT_LAUNCH_PIPE_W(0); break;
             }
+#undef VT_LAUNCH_PIPE_W
 #undef VT_LAUNCH_PIPE
             return;
         }
