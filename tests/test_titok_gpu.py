@@ -196,3 +196,106 @@ def test_autoencoder_large_registry_surface_and_step(vt):
     out.float().abs().mean().backward()
     g = m.encoder.model_layers.attn_layer[0].to_qkv.weight.grad
     assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ first-token family, mask variants
+def test_first_token_autoencoder_matches_oracle(vt):
+    """`AutoEncoder_first_token` (autoencoder.py:672-913) at a reduced clip: 8x32x32 video, 32 latents + 16 first-frame latents,
+    tiny stacks; video encoder, first-frame encoder (patch (1, 8, 8)), the shared FSQ and Decoder_unify (blocks.py:690-787) against
+    oracle/titok_oracle.py::first_token_forward.  The decoder's rotary table is the FIXED one (the reference's hard-coded 2560-row
+    table does not fit its own sequence and raises): same construction on both sides, documented in DESIGN.md."""
+    cfg = T.make_first_token_cfg("tiny", "tiny", frames=8, side=32, tokens=32, cond_tokens=16)
+    sd = T.init_first_token_state_dict(cfg)
+
+    class M(vt.titok._AutoEncoderFirstToken):
+        ENC_SIZE, DEC_SIZE, TOKENS = "tiny", "tiny", 32
+    m = M(_geometry=dict(in_grid=[8, 32, 32], patch_size=[4, 8, 8], tokens=32, cond_tokens=16))
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    video = torch.from_numpy(gen.video_clips(4, 8, 32, 720))     # B = 4: every stack's B * L is a multiple of 64 (128 / 256 / 320 rows)
+    up = torch.from_numpy(gen.normal((4, 3, 8, 32, 32), 721))
+    x_q, first_q = m.encode(video.cuda())
+    assert x_q.shape == (4, 32, 6) and first_q.shape == (4, 16, 6)
+    out = m(video.cuda())["pred_frames"]
+    assert out.shape == video.shape
+    (out * up.cuda()).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    free = T.first_token_forward(sd, cfg, video, emu=True)
+    assert float((free["codes"] == x_q.detach().cpu().float()).float().mean()) >= 0.8      # FSQ near-ties may flip under bf16
+    ref = T.first_token_forward(p, cfg, video, emu=True, force_codes=x_q.detach().cpu().float(), force_first=first_q.detach().cpu().float())
+    with torch.no_grad():
+        exact = T.first_token_forward(sd, cfg, video, emu=False, force_codes=x_q.detach().cpu().float(), force_first=first_q.detach().cpu().float())
+    gap = rel(ref["pred_frames"], exact["pred_frames"])
+    tol = max(3e-2, 1.5 * gap)
+    assert rel(out, ref["pred_frames"]) < tol, (gap, tol)
+    (ref["pred_frames"] * up).sum().backward()
+    worst = max((rel(q.grad, p[k].grad), k) for k, q in m.named_parameters())
+    assert worst[0] < 4 * tol, worst
+    with torch.no_grad():
+        idx = m.quantize(m.encoder(video.cuda()))[1]["indices"]
+        idx1 = m.quantize(m.encoder1(video.cuda()[:, :, 0:1]))[1]["indices"]
+        again = m.decode_indices(idx, idx1)
+    assert rel(again, out) < 1e-6
+
+
+def test_unify_rotary_table_follows_get_freqs_multi_construction(vt):
+    """the decoder's positions: pair 0's latents at (i, i, i); pair 1 offset by pair 0's largest coordinate (rope.py:134-136);
+    product table == oracle angles"""
+    pos = vt.titok.rope_positions_unify(256, 512, [4, 16, 16])
+    assert pos.shape == (256 + 512 + 1024, 3)
+    assert np.array_equal(pos[:256, 0], np.arange(256)) and np.array_equal(pos[:256, 1], pos[:256, 2])
+    off = 15 + 256                                                     # max coordinate of get_grid([1,16,16], 256)
+    assert np.array_equal(pos[256:768, 0], np.arange(512) + off)
+    assert pos[768].tolist() == [512 + off, 512 + off, 512 + off] and pos[-1].tolist() == [3 + 512 + off, 15 + 512 + off, 15 + 512 + off]
+    cos, sin = vt.titok.rope_tables_from_positions(vt.titok.rope_positions_unify(16, 32, [2, 4, 4]))
+    ang = T.rope_angles_unify(16, 32, [2, 4, 4], 64)
+    assert torch.allclose(cos.double(), torch.cos(ang), atol=1e-6) and torch.allclose(sin.double(), torch.sin(ang), atol=1e-6)
+
+
+@pytest.mark.parametrize("name,mask_shape", [("autoencoder_mask3", (1, 1, 256)), ("autoencoder_convpatchify_mask2", (1, 32, 256))])
+def test_mask_token_variants_match_oracle(vt, name, mask_shape):
+    """Encoder4/Decoder4 ((1, 1, width) mask token) and Encoder1/Decoder1 (one learned token per position): the same stacks with a
+    differently shaped mask parameter (blocks.py:324,380,456,512); whole model vs the oracle, mask-token gradients included"""
+    kind = {"autoencoder_mask3": "vector", "autoencoder_convpatchify_mask2": "full"}[name]
+    cfg = T.make_cfg("tiny", frames=8, side=32, tokens=32)
+    sd = T.init_state_dict(cfg, seed=790)
+    sd["encoder.mask_token"] = torch.from_numpy(gen.normal(mask_shape, 791, 256 ** -0.5))
+    sd["decoder.mask_token"] = torch.from_numpy(gen.normal((1, 1 if kind == "vector" else 32, 256), 792, 256 ** -0.5))
+
+    class M(vt.titok._AutoEncoderBase):
+        MODEL_SIZE, LEVELS, MASK = "tiny", [8, 8, 8, 5, 5, 5], kind
+    m = M(_geometry=dict(in_grid=[8, 32, 32], patch_size=[4, 8, 8], tokens=32))
+    assert tuple(m.encoder.mask_token.shape) == mask_shape
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    video = torch.from_numpy(gen.video_clips(2, 8, 32, 793))
+    up = torch.from_numpy(gen.normal((2, 3, 8, 32, 32), 794))
+    codes, _ = m.encode(video.cuda())
+    out = m(video.cuda())["pred_frames"]
+    (out * up.cuda()).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = T.autoencoder_forward(p, cfg, video, emu=True, force_codes=codes.detach().cpu().float())
+    with torch.no_grad():
+        exact = T.autoencoder_forward(sd, cfg, video, emu=False, force_codes=codes.detach().cpu().float())
+    tol = max(3e-2, 1.5 * rel(ref["pred_frames"], exact["pred_frames"]))
+    assert rel(out, ref["pred_frames"]) < tol
+    (ref["pred_frames"] * up).sum().backward()
+    for k in ("encoder.mask_token", "decoder.mask_token"):
+        assert rel(dict(m.named_parameters())[k].grad, p[k].grad) < 4 * tol, k
+    assert vt.models[name].MASK == kind
+
+
+def test_first_token_registry_names_resolve_and_run_at_the_reference_geometry(vt):
+    """cfgs/larp_tokenizerf256t512.yaml:37 -> `autoencoder_first_token_f256t512` at the hard-coded 16x128x128 geometry: 512 + 256 latent
+    tokens, base stacks; one clip forward + backward, finite.  The yaml-only name `..._f256t1024` resolves to the t1024a class."""
+    assert vt.models["autoencoder_first_token_f256t1024"] is vt.models["autoencoder_first_token_f256t1024a"]
+    m = vt.make({"name": "autoencoder_first_token_f256t512", "args": {"bottleneck": {"name": "bottleneck"}, "prior_model": None, "input_size": 128}}).cuda()
+    assert m.decoder.freqs[0].shape[0] == 256 + 512 + 1024 and m.encoder1.out_tokens == 256 and m.quantize.codebook_size == 64000
+    video = torch.from_numpy(gen.video_clips(1, 16, 128, 730)).cuda()
+    out = m(video)["pred_frames"]
+    assert out.shape == (1, 3, 16, 128, 128)
+    out.float().abs().mean().backward()
+    # (proj_cond.WEIGHT can be exactly zero here: a freshly initialised first-frame encoder emits ~0, which FSQ rounds to the all-zero code)
+    for g in (m.encoder1.model_layers.attn_layer[0].to_qkv.weight.grad, m.decoder.proj_cond.bias.grad, m.encoder.proj_in.weight.grad):
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0

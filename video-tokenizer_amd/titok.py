@@ -1,5 +1,8 @@
 """The reference's TiTok-style FSQ autoencoders (`autoencoder_convpatchify`, `autoencoder_convpatchify_greatfsq`,
-`autoencoder_large`: models/model_new/autoencoder.py:8-87, 89-170, 589-669) on the MI355X kernels.  SURVEY §8f rank 3.
+`autoencoder_large`: models/model_new/autoencoder.py:8-87, 89-170, 589-669; the mask-token variants `autoencoder_mask3`,
+`autoencoder_convpatchify_mask2[_greatfsq]`: :173-416; and `autoencoder_first_token_f256t512 / t768 / t1024a` with
+`Decoder_unify`: :672-913, base/blocks.py:690-787 -- what the f256t* yamls name) on the MI355X kernels.  SURVEY §8f rank 3.
+Not built: `autoencoder_convpatchify_simplytransformer` (a different layer type, base/simpletransformer.py).
 
 Same module tree and state-dict keys as the reference (`encoder.proj_in`, `encoder.mask_token`,
 `encoder.model_layers.attn_layer.{i}.{to_qkv,q_norm,k_norm,out_proj}`, `encoder.model_layers.ffd_layer.{i}.{0,1,3}`,
@@ -43,20 +46,24 @@ def ffd_inner_dim(dim, mult=4, mult_of=32):
     return mult_of * ((inner + mult_of - 1) // mult_of)
 
 
-def rope_tables(in_tokens, in_grid, head_dim=64, theta=10000.0):
-    """get_freqs (models/model_new/base/rope.py:108-121) as fp32 (cos, sin) tables [L, head_dim/2], L = in_tokens + prod(grid).
-    Latent row i sits at (i, i, i); grid token (t, h, w) at (t, h, w) + in_tokens (:49-84).  Axis dims [24, 20, 20] for
-    head_dim 64; per-axis angle = pos * (pi/2) * theta**linspace(0, 1, n) in float64 (:27-46); the three axes are interleaved
-    T H W T H W ... with the temporal leftovers last (:87-105)."""
-    per = head_dim / 3
-    dims = [int(per - (per % 2))] * 3
-    dims[0] += head_dim - sum(dims)
+def rope_positions(in_tokens, in_grid):
+    """get_grid (models/model_new/base/rope.py:49-84): float64 [in_tokens + prod(grid), 3]; latent row i sits at (i, i, i), grid token
+    (t, h, w) at (t, h, w) + in_tokens"""
     f, h, w = in_grid
-    n_grid = f * h * w
-    pos = np.zeros((in_tokens + n_grid, 3), dtype=np.float64)
+    pos = np.zeros((in_tokens + f * h * w, 3), dtype=np.float64)
     pos[:in_tokens] = np.arange(in_tokens, dtype=np.float64)[:, None]
     tt, hh, ww = np.meshgrid(np.arange(f), np.arange(h), np.arange(w), indexing="ij")
     pos[in_tokens:] = np.stack([tt.ravel(), hh.ravel(), ww.ravel()], axis=1) + in_tokens
+    return pos
+
+
+def rope_tables_from_positions(pos, head_dim=64, theta=10000.0):
+    """fp32 (cos, sin) tables [L, head_dim/2] of the 3-axis rotary embedding at positions pos [L, 3] (rope.py:27-46, 87-121): axis
+    dims [24, 20, 20] for head_dim 64; per-axis angle = pos * (pi/2) * theta**linspace(0, 1, n) in float64; the three axes are
+    interleaved T H W T H W ... with the temporal leftovers last."""
+    per = head_dim / 3
+    dims = [int(per - (per % 2))] * 3
+    dims[0] += head_dim - sum(dims)
     axes = []
     for a, dim in enumerate(dims):
         fr = torch.linspace(math.log(1.0, theta), math.log(theta, theta), dim // 2, dtype=torch.float64).numpy()
@@ -70,6 +77,26 @@ def rope_tables(in_tokens, in_grid, head_dim=64, theta=10000.0):
         cols += [axes[a][:, j] for j in range(n_short, axes[a].shape[1])]
     ang = np.stack(cols, axis=1)
     return torch.from_numpy(np.cos(ang).astype(np.float32)), torch.from_numpy(np.sin(ang).astype(np.float32))
+
+
+def rope_tables(in_tokens, in_grid, head_dim=64, theta=10000.0):
+    """get_freqs (rope.py:108-121) as fp32 (cos, sin) tables [L, head_dim/2], L = in_tokens + prod(grid)"""
+    return rope_tables_from_positions(rope_positions(in_tokens, in_grid), head_dim, theta)
+
+
+def rope_positions_unify(cond_tokens, in_tokens, grid):
+    """Positions of Decoder_unify's sequence [cond latents | latents | grid tokens].
+
+    The reference builds its table with get_freqs_multi([[256, [1,16,16]], [1024, [4,16,16]]]) (blocks.py:724-736), i.e. for
+    the rows [256 first-frame latents | 256 first-frame grid tokens | 1024 latents | 1024 grid tokens] = 2560 rows, hard-coded,
+    while the sequence it is applied to has cond + in_tokens + grid = 2304 / 2048 / 1792 rows: apply_rotary_emb (rope.py:18-24)
+    cannot broadcast the two and raises -- as shipped none of the autoencoder_first_token_* models can run a forward pass.
+    This build keeps get_freqs_multi's construction (pair i is offset by the maximum coordinate of pair i-1, rope.py:134-136) and
+    takes the rows of the tokens that are actually present: the latents of pair 0 (the first-frame GRID rows have no token in the
+    decoder), then pair 1 = [in_tokens latents | grid] with the model's own in_tokens."""
+    p0 = rope_positions(cond_tokens, [1, grid[1], grid[2]])
+    p1 = rope_positions(in_tokens, grid) + p0.max()
+    return np.concatenate([p0[:cond_tokens], p1], axis=0)
 
 
 def pack_layer_weights(w_qkv, w_out, w_fc1, w_fc2):
@@ -248,6 +275,13 @@ def init_weights(module):
         nn.init.zeros_(module.bias)
 
 
+def _mask_shape(kind, n, width):
+    """the reference's block variants differ only in the shape of the learned mask token that is expanded to [B, n, width]:
+    Encoder/Decoder (1, 1, 1) (blocks.py:47,103), Encoder4/Decoder4 (1, 1, width) ('mask3', :456,512), Encoder1/Decoder1 (1, n, width)
+    ('mask2', :324,380)"""
+    return {"scalar": (1, 1, 1), "vector": (1, 1, width), "full": (1, n, width)}[kind]
+
+
 class _RopeMixin:
     def _freqs(self, device):
         if self._freqs_dev is None or self._freqs_dev[0].device != device:
@@ -259,14 +293,14 @@ class Encoder(nn.Module, _RopeMixin):
     """blocks.py:18-82: Conv3d patchify, `out_tokens` scalar mask tokens in FRONT of the patch tokens, layers, first
     out_tokens rows -> Linear(width, token_size)"""
 
-    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=3, out_channels=5, in_grid=(16, 128, 128), out_tokens=2048):
+    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=3, out_channels=5, in_grid=(16, 128, 128), out_tokens=2048, mask="scalar"):
         super().__init__()
         self.patch_size, self.token_size, self.in_channels, self.out_tokens = tuple(patch_size), out_channels, in_channels, out_tokens
         self.grid = [x // y for x, y in zip(in_grid, patch_size)]
         self.width, self.num_layers, self.heads, mlp_ratio = get_model_dims(model_size)
         assert patch_size[1] == patch_size[2] and in_grid[1] == in_grid[2], "square frames and patches (the reference's only geometry)"
         self.proj_in = nn.Conv3d(in_channels, self.width, kernel_size=self.patch_size, stride=self.patch_size, bias=True)
-        self.mask_token = nn.Parameter(self.width ** -0.5 * torch.randn(1, 1, 1))
+        self.mask_token = nn.Parameter(self.width ** -0.5 * torch.randn(*_mask_shape(mask, out_tokens, self.width)))
         self.freqs = rope_tables(out_tokens, self.grid, head_dim=self.width // self.heads)
         self._freqs_dev = None
         self.model_layers = ResidualAttentionBlock(self.width, self.heads, mlp_ratio, self.num_layers)
@@ -285,7 +319,7 @@ class Decoder(nn.Module, _RopeMixin):
     """blocks.py:85-149: Linear(token_size, width), grid_size scalar mask tokens BEHIND the latents, layers, last grid_size
     rows -> ConvTranspose3d unpatchify"""
 
-    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=5, out_channels=3, in_tokens=2048, out_grid=(32, 256, 256)):
+    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=5, out_channels=3, in_tokens=2048, out_grid=(32, 256, 256), mask="scalar"):
         super().__init__()
         self.patch_size, self.token_size, self.in_channels, self.in_tokens = tuple(patch_size), in_channels, out_channels, in_tokens
         self.out_grid = tuple(out_grid)
@@ -294,7 +328,7 @@ class Decoder(nn.Module, _RopeMixin):
         self.width, self.num_layers, self.heads, mlp_ratio = get_model_dims(model_size)
         assert patch_size[1] == patch_size[2] and out_grid[1] == out_grid[2], "square frames and patches (the reference's only geometry)"
         self.proj_in = nn.Linear(self.token_size, self.width, bias=True)
-        self.mask_token = nn.Parameter(self.width ** -0.5 * torch.randn(1, 1, 1))
+        self.mask_token = nn.Parameter(self.width ** -0.5 * torch.randn(*_mask_shape(mask, self.grid_size, self.width)))
         self.freqs = rope_tables(in_tokens, self.grid, head_dim=self.width // self.heads)
         self._freqs_dev = None
         self.model_layers = ResidualAttentionBlock(self.width, self.heads, mlp_ratio, self.num_layers)
@@ -310,10 +344,105 @@ class Decoder(nn.Module, _RopeMixin):
         return ConvTransposePatch.apply(h[:, self.in_tokens:], self.proj_out.weight, self.proj_out.bias, geom)
 
 
+class DecoderUnify(nn.Module, _RopeMixin):
+    """`Decoder_unify` (blocks.py:690-787): sequence [proj_cond(first-frame latents) | proj_in(latents) | grid_size mask tokens], layers,
+    last grid_size rows -> ConvTranspose3d.  Two shipped quirks are NOT reproduced (see rope_positions_unify and DESIGN.md): the
+    hard-coded 2560-row rotary table that makes the reference's forward raise, and the debug print in forward (:776)."""
+
+    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=5, out_channels=3, in_tokens=1024, cond_tokens=256, out_grid=(16, 128, 128)):
+        super().__init__()
+        self.patch_size, self.token_size, self.in_channels = tuple(patch_size), in_channels, out_channels
+        self.in_tokens, self.cond_tokens, self.out_grid = in_tokens, cond_tokens, tuple(out_grid)
+        self.grid = [x // y for x, y in zip(out_grid, patch_size)]
+        self.grid_size = math.prod(self.grid)
+        self.width, self.num_layers, self.heads, mlp_ratio = get_model_dims(model_size)
+        assert patch_size[1] == patch_size[2] and out_grid[1] == out_grid[2], "square frames and patches (the reference's only geometry)"
+        self.proj_in = nn.Linear(self.token_size, self.width, bias=True)
+        if self.cond_tokens > 0:
+            self.proj_cond = nn.Linear(self.token_size, self.width, bias=True)
+        self.mask_token = nn.Parameter(self.width ** -0.5 * torch.randn(1, 1, 1))
+        self.freqs = rope_tables_from_positions(rope_positions_unify(cond_tokens, in_tokens, self.grid), head_dim=self.width // self.heads)
+        self._freqs_dev = None
+        self.model_layers = ResidualAttentionBlock(self.width, self.heads, mlp_ratio, self.num_layers)
+        self.proj_out = nn.ConvTranspose3d(self.width, out_channels, kernel_size=self.patch_size, stride=self.patch_size, bias=True)
+        self.apply(init_weights)
+
+    def forward(self, x, cond=None):
+        if self.cond_tokens > 0 and cond is None:
+            raise NotImplementedError("Decoder_unify without the first-frame tokens: the rotary table is built for [cond | latents | grid]")
+        B = x.shape[0]
+        toks = []
+        if self.cond_tokens > 0:
+            toks.append(LinearFn.apply(cond, self.proj_cond.weight, self.proj_cond.bias))
+        toks.append(LinearFn.apply(x, self.proj_in.weight, self.proj_in.bias))
+        toks.append(self.mask_token.expand(B, self.grid_size, self.width))
+        h = self.model_layers(torch.cat(toks, dim=1), freqs=self._freqs(x.device))
+        prefix = self.in_tokens + self.cond_tokens
+        geom = (B, self.in_channels, self.out_grid[0], self.out_grid[1], self.patch_size[0], self.patch_size[1])
+        return ConvTransposePatch.apply(h[:, prefix:], self.proj_out.weight, self.proj_out.bias, geom)
+
+
+class _AutoEncoderFirstToken(nn.Module):
+    """`AutoEncoder_first_token` (autoencoder.py:672-913; what cfgs/larp_tokenizerf256t512.yaml / t768 / t1024 name): a video encoder,
+    a first-frame encoder (patch (1, 8, 8), 256 tokens), ONE shared FSQ, Decoder_unify conditioned on the first-frame codes.
+    The reference ignores every constructor keyword; `_geometry` = dict(in_grid, patch_size, tokens, cond_tokens) is for small tests."""
+    ENC_SIZE, DEC_SIZE, TOKENS, LEVELS = "base", "base", 512, [8, 8, 8, 5, 5, 5]
+    output_format = "bcthw"
+
+    def __init__(self, bottleneck=None, prior_model=None, _geometry=None, **kwargs):
+        super().__init__()
+        g = dict(in_grid=[16, 128, 128], patch_size=[4, 8, 8], tokens=self.TOKENS, cond_tokens=256)
+        g.update(_geometry or {})
+        token_size = len(self.LEVELS)
+        grid, ps = g["in_grid"], g["patch_size"]
+        self.encoder = Encoder(model_size=self.ENC_SIZE, patch_size=ps, in_channels=3, out_channels=token_size, in_grid=grid, out_tokens=g["tokens"])
+        self.encoder1 = Encoder(model_size=self.ENC_SIZE, patch_size=[1, ps[1], ps[2]], in_channels=3, out_channels=token_size,
+                                in_grid=[1, grid[1], grid[2]], out_tokens=g["cond_tokens"])
+        self.quantize = FSQ(levels=self.LEVELS)
+        self.decoder = DecoderUnify(model_size=self.DEC_SIZE, patch_size=ps, in_channels=token_size, out_channels=3, in_tokens=g["tokens"],
+                                    cond_tokens=g["cond_tokens"], out_grid=grid)
+        self.prior_model = None
+
+    def encode(self, data, **kwargs):
+        x_q, _ = self.quantize(self.encoder(data))
+        first_q, _ = self.quantize(self.encoder1(data[:, :, 0:1]))
+        return x_q, first_q
+
+    def decode(self, x, first_token):
+        return self.decoder(x, first_token)
+
+    def decode_indices(self, indices, first_indices):
+        return self.decoder(self.quantize.indices_to_codes(indices), self.quantize.indices_to_codes(first_indices))
+
+    def forward(self, x):
+        x_q, first_q = self.encode(x)
+        return {"pred_frames": self.decode(x_q, first_q)}
+
+
+@register("autoencoder_first_token_f256t512")
+class AutoEncoderFirstTokenT512(_AutoEncoderFirstToken):
+    ENC_SIZE, DEC_SIZE, TOKENS = "base", "base", 512
+
+
+@register("autoencoder_first_token_f256t768")
+class AutoEncoderFirstTokenT768(_AutoEncoderFirstToken):
+    ENC_SIZE, DEC_SIZE, TOKENS = "base", "base", 768
+
+
+@register("autoencoder_first_token_f256t1024a")
+class AutoEncoderFirstTokenT1024(_AutoEncoderFirstToken):
+    ENC_SIZE, DEC_SIZE, TOKENS = "small_thin", "small", 1024
+
+
+# cfgs/larp_tokenizerf256t1024.yaml:37 names `autoencoder_first_token_f256t1024`, which the reference never registers (only
+# `...t1024a`, autoencoder.py:672): models.make raises KeyError there.  Registered here as an alias so the shipped yaml resolves.
+register("autoencoder_first_token_f256t1024")(AutoEncoderFirstTokenT1024)
+
+
 class _AutoEncoderBase(nn.Module):
     """autoencoder.py:9-87 / 90-170 / 590-669: every size keyword of the reference constructor is accepted and ignored (the
     reference hard-codes the geometry); `_geometry` = dict(in_grid, patch_size, tokens) overrides it for small tests."""
-    MODEL_SIZE, LEVELS = "small", [8, 8, 8, 5, 5, 5]
+    MODEL_SIZE, LEVELS, MASK = "small", [8, 8, 8, 5, 5, 5], "scalar"
     output_format = "bcthw"
 
     def __init__(self, bottleneck=None, prior_model=None, _geometry=None, **kwargs):
@@ -322,10 +451,10 @@ class _AutoEncoderBase(nn.Module):
         g.update(_geometry or {})
         token_size = len(self.LEVELS)
         self.encoder = Encoder(model_size=self.MODEL_SIZE, patch_size=g["patch_size"], in_channels=3, out_channels=token_size,
-                               in_grid=g["in_grid"], out_tokens=g["tokens"])
+                               in_grid=g["in_grid"], out_tokens=g["tokens"], mask=self.MASK)
         self.quantize = FSQ(levels=self.LEVELS)
         self.decoder = Decoder(model_size=self.MODEL_SIZE, patch_size=g["patch_size"], in_channels=token_size, out_channels=3,
-                               in_tokens=g["tokens"], out_grid=g["in_grid"])
+                               in_tokens=g["tokens"], out_grid=g["in_grid"], mask=self.MASK)
         self.prior_model = None
 
     def encode(self, data, **kwargs):
@@ -355,3 +484,21 @@ class AutoEncoderConvPatchifyGreatFSQ(_AutoEncoderBase):
 @register("autoencoder_large")
 class AutoEncoderLarge(_AutoEncoderBase):
     MODEL_SIZE, LEVELS = "large", [8, 8, 8, 5, 5, 5]
+
+
+@register("autoencoder_convpatchify_mask2")
+class AutoEncoderMask2(_AutoEncoderBase):
+    """autoencoder.py:256-335: Encoder1 / Decoder1 = one learned mask token per position"""
+    MODEL_SIZE, LEVELS, MASK = "base", [8, 8, 8, 5, 5, 5], "full"
+
+
+@register("autoencoder_convpatchify_mask2_greatfsq")
+class AutoEncoderMask2GreatFSQ(_AutoEncoderBase):
+    """autoencoder.py:337-416"""
+    MODEL_SIZE, LEVELS, MASK = "base", [8, 8, 8, 8, 5, 5, 5, 5], "full"
+
+
+@register("autoencoder_mask3")
+class AutoEncoderMask3(_AutoEncoderBase):
+    """autoencoder.py:173-254: Encoder4 / Decoder4 = one learned width-vector shared by all positions"""
+    MODEL_SIZE, LEVELS, MASK = "base", [8, 8, 8, 5, 5, 5], "vector"
