@@ -113,9 +113,16 @@ def fsq_autoencoder_step(vt, name, steps, warmup, clips=4):
     bf16 operand copies of the weights are re-used between steps; `tflops` counts the layers' matrix products only."""
     m = vt.make({"name": name, "args": {"bottleneck": None, "prior_model": None}}).cuda()
     video = torch.from_numpy(vt.config.synthetic_clips(clips, 16, 128, 7)).cuda()
-    W, layers, L = m.encoder.width, m.encoder.num_layers, 2048
-    inner = vt.titok.ffd_inner_dim(W)
-    flops = 3 * 2 * layers * (2 * L * W * (4 * W + W + 3 * inner) + 4 * L * L * W)
+    # matrix-product flops of every layer stack of the model (encoder, first-frame encoder, decoder): per layer and row
+    # 2 * W * (4W + W + 3 * inner) for the four projections + 4 * L * W for the two attention products; fwd + bwd = 3x
+    flops = 0
+    for st in (getattr(m, "encoder", None), getattr(m, "encoder1", None), getattr(m, "decoder", None)):
+        if st is None:
+            continue
+        W, layers = st.width, st.num_layers
+        L = st.freqs[0].shape[0]
+        inner = st.model_layers.ffd_layer[0][3].weight.shape[1]
+        flops += 3 * layers * (2 * L * W * (4 * W + W + 3 * inner) + 4 * L * L * W)
 
     def step():
         for q in m.parameters():

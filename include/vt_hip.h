@@ -77,6 +77,9 @@ typedef struct {
                                                 sums of the bf16-rounded output over rows [192 t, 192 t + 192) (fixed
                                                 order, no atomics).  vt_sum_slabs over the rows gives the bias gradient
                                                 of the Linear whose pre-activation is `aux`, without re-reading `out` */
+    float out_scale;                         /* VT_EPI_F32 only: 0 = none; otherwise the finished value (after bias, rounding, residual,
+                                                rowmod) is multiplied by it -- the 1/sqrt(i+1) rescale of the residual stream after
+                                                layer i of models/model_new/base/transformer.py:88-90 -- before out / out2 are written */
     int32_t tile;                            /* tile generation for THIS call: 0 = automatic (use this; 192x192x64 tiles on a
                                                 3-stage LDS-DMA ring, one persistent workgroup per CU, when the problem fills
                                                 them, else 128x128x64).  Tests / tuning: 1 = force 128, 2 = force 192, 5 = 192x96
@@ -264,6 +267,31 @@ int vt_sigmoid_gate_fwd(const void* o, const void* qkvg, int64_t M, int32_t D, v
 int vt_sigmoid_gate_bwd(const void* dog, const void* o, const void* qkvg, int64_t M, int32_t D, void* d_o, void* dqkvg, vtStream stream);
 int vt_geglu_fwd(const void* h, int64_t M, int32_t I, void* a, int64_t lda, vtStream stream);
 int vt_geglu_bwd(const void* da, int64_t lda, const void* h, int64_t M, int32_t I, void* dh, vtStream stream);
+/* dst[r, :] = scale * src[r, :] (fp32, may be in place) and/or its bf16 copy: the incoming gradient of a layer whose output was
+ * rescaled by 1/sqrt(i+1), produced once for the fp32 residual path and the bf16 GEMM operand.  dim % 4 == 0. */
+int vt_scale_rows(const float* src, float scale, int64_t rows, int32_t dim, float* dst_f32, void* dst_bf16, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A stack of those layers as ONE enqueue per direction: `ResidualAttentionBlock.forward` (transformer.py:66-91) and the
+ * backward autograd derives for it -- x <- (x + Attn(x)); x <- (x + ffd(x)); x <- x / sqrt(i+1) for i = 0..depth-1 -- the
+ * transformer of every `autoencoder_*` model (Encoder / Decoder / Decoder_unify, base/blocks.py).  Per layer forward: cast,
+ * 4 GEMMs, vt_qknorm_rope_fwd, vt_attention_fwd, vt_sigmoid_gate_fwd, vt_layernorm_fwd, vt_geglu_fwd (11 launches); backward
+ * 16 launches + one grouped weight-gradient launch.  The caller owns parameters / gradients (fp32, the reference's layout:
+ * to_qkv [4D, D], q/k_norm [64], out_proj [D, D], ffd LayerNorm [D], ffd.1 [2 inner, D], ffd.3 [D, inner]), the rotary tables
+ * (fp32 [L, 32] each) and one workspace per forward whose backward is pending.  B * L % 64 == 0, D = 64 H.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int32_t B, L, D, H, depth, inner; } vtGatedStackConfig;
+typedef struct { float *to_qkv_w, *q_norm_w, *q_norm_b, *k_norm_w, *k_norm_b, *out_proj_w, *ln_w, *ln_b, *fc1_w, *fc2_w; } vtGatedLayerTensors;
+typedef struct vtGatedStack vtGatedStack;
+int vt_gated_stack_create(const vtGatedStackConfig* cfg, vtGatedStack** out);
+void vt_gated_stack_destroy(vtGatedStack* st);
+size_t vt_gated_stack_workspace_bytes(const vtGatedStack* st);
+int vt_gated_stack_init_workspace(vtGatedStack* st, void* ws, vtStream stream);
+/* repack != 0: refresh the bf16 operand copies of the weights first (after an optimizer step / load_state_dict) */
+int vt_gated_stack_forward(vtGatedStack* st, const vtGatedLayerTensors* layers_host, const float* cos_tab, const float* sin_tab,
+                           const float* x_in, void* ws, float* x_out, int32_t repack, vtStream stream);
+int vt_gated_stack_backward(vtGatedStack* st, const vtGatedLayerTensors* layers_host, const float* cos_tab, const float* sin_tab,
+                            const float* dy, void* ws, const vtGatedLayerTensors* grads_host, float* dx, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused Adam (+ optional EMA) over flat fp32 buffers: replaces optimizer.step() of torch.optim.Adam

@@ -299,3 +299,39 @@ def test_first_token_registry_names_resolve_and_run_at_the_reference_geometry(vt
     # (proj_cond.WEIGHT can be exactly zero here: a freshly initialised first-frame encoder emits ~0, which FSQ rounds to the all-zero code)
     for g in (m.encoder1.model_layers.attn_layer[0].to_qkv.weight.grad, m.decoder.proj_cond.bias.grad, m.encoder.proj_in.weight.grad):
         assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+
+
+def test_gated_stack_engine_equals_python_composition(vt, monkeypatch):
+    """vt_gated_stack_forward / _backward (one C++ enqueue per direction) == the per-layer Python composition of the same
+    kernels (titok.GatedLayer), bit for bit: output, input gradient and every parameter gradient of a 4-layer stack, incl.
+    the fused 1/sqrt(i+1) rescale (vtGemmNT.out_scale) and the 64-padded GEGLU width (inner 704 -> 704, 1376 -> 1408)."""
+    for width, heads in ((256, 4), (512, 8)):
+        torch.manual_seed(0)
+        blk = vt.titok.ResidualAttentionBlock(width, heads, 4, 4).cuda()
+        for p_ in blk.parameters():
+            torch.nn.init.normal_(p_, 0.0, 0.05) if p_.dim() > 1 else torch.nn.init.normal_(p_, 1.0 if "norm" in "" else 0.5, 0.1)
+        cos, sin = vt.titok.rope_tables(32, [2, 4, 4])
+        x = torch.from_numpy(gen.normal((2, 64, width), 901, 0.5)).cuda()
+        up = torch.from_numpy(gen.normal((2, 64, width), 902)).cuda()
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("VT_GATED_PYTHON", mode)
+            for p_ in blk.parameters():
+                p_.grad = None
+            xi = x.clone().requires_grad_(True)
+            out = blk(xi, (cos.cuda(), sin.cuda()))
+            (out * up).sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = (out.detach().clone(), xi.grad.clone(), {n: p_.grad.clone() for n, p_ in blk.named_parameters()})
+        assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+        for n in res["0"][2]:
+            assert torch.equal(res["0"][2][n], res["1"][2][n]), n
+        # a second forward/backward through the pooled workspace (weights unchanged: no re-pack) gives the same bits
+        monkeypatch.setenv("VT_GATED_PYTHON", "0")
+        xi = x.clone().requires_grad_(True)
+        out = blk(xi, (cos.cuda(), sin.cuda()))
+        assert torch.equal(out, res["0"][0])
+        with torch.no_grad():                       # and after a weight update the packed copies follow
+            blk.attn_layer[0].to_qkv.weight.mul_(1.01)
+        out2 = blk(x, (cos.cuda(), sin.cuda()))
+        assert not torch.equal(out2, res["0"][0])

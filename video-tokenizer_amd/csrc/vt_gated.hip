@@ -301,3 +301,26 @@ extern "C" int vt_geglu_bwd(const void* da, int64_t lda, const void* h, int64_t 
     VT_CHECK_LAUNCH("vt_geglu_bwd");
     return VT_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ scaled copy of gradient rows
+namespace {
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ src, float scale, int64_t n4, float* __restrict__ dst, bf16_t* __restrict__ dstb) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = ((const f32x4*)src)[i];
+        v *= scale;
+        if (dst) ((f32x4*)dst)[i] = v;
+        if (dstb) ((bf16x4*)dstb)[i] = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    }
+}
+}  // namespace
+
+extern "C" int vt_scale_rows(const float* src, float scale, int64_t rows, int32_t dim, float* dst_f32, void* dst_bf16, vtStream stream) {
+    VT_CHECK_ARG(src && (dst_f32 || dst_bf16) && rows > 0 && dim > 0 && dim % 4 == 0, "vt_scale_rows: bad arguments (dim %% 4 == 0)");
+    VT_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst_f32) & 15) == 0 && ((uintptr_t)dst_bf16 & 7) == 0, "vt_scale_rows: unaligned pointer");
+    const int64_t n4 = rows * dim / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, scale, n4, dst_f32, (bf16_t*)dst_bf16);
+    VT_CHECK_LAUNCH("vt_scale_rows");
+    return VT_OK;
+}

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
                     const int64_t orow = omap(m);
                     if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldr + n);
                     if (p.rowmod) v += *(const f32x4*)(p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n);
+                    if (p.out_scale != 0.f) v *= p.out_scale;
                     *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
                     if (p.out2) st_stream((bf16x4*)((bf16_t*)p.out2 + orow * p.ldo2 + n), (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])});
                 }
@@ -333,6 +334,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     VT_CHECK_ARG(!p.rowmod || p.N % 4 == 0, "vt_gemm_nt: rowmod needs N %% 4 == 0");
     if (p.epi == VT_EPI_BF16_GELU) VT_CHECK_ARG(p.out2 && p.ldo2 % 4 == 0, "vt_gemm_nt: GELU epilogue needs out2");
     if (p.epi == VT_EPI_BF16_DGELU) VT_CHECK_ARG(p.aux && p.ldaux % 4 == 0, "vt_gemm_nt: DGELU epilogue needs aux");
+    VT_CHECK_ARG(p.out_scale == 0.f || p.epi == VT_EPI_F32, "vt_gemm_nt: out_scale only with VT_EPI_F32");
     VT_CHECK_ARG(!p.colsum_partial || (p.epi == VT_EPI_BF16_DGELU && p.N % 4 == 0),
                  "vt_gemm_nt: colsum_partial needs the DGELU epilogue and N %% 4 == 0 (it always runs on the 192-row tile kernel)");
     if (p.epi == VT_EPI_F32) {

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     const int64_t orow = omap(m);
                     if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldr + n);
                     if (p.rowmod) v += *(const f32x4*)(p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n);
+                    if (p.out_scale != 0.f) v *= p.out_scale;
                     *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
                     if (p.out2) st_stream((bf16x4*)((bf16_t*)p.out2 + orow * p.ldo2 + n), (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])});
                 }

@@ -28,6 +28,7 @@ __device__ __forceinline__ void nt_epilogue(const vtGemmNT& p, const RowMap& oma
             if (p.round_bf16) v = (f32x4){round_bf16(v[0]), round_bf16(v[1]), round_bf16(v[2]), round_bf16(v[3])};
             if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldr + n);   // (a streaming load of these 64-B line halves fetches every line twice)
             if (p.rowmod) v += *(const f32x4*)(p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n);
+            if (p.out_scale != 0.f) v *= p.out_scale;
             *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;   // 64-B pieces of a line per instruction: a streaming store would lose the L2's write combining (+45 %)
             if (p.out2) *(bf16x4*)((bf16_t*)p.out2 + orow * p.ldo2 + n) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         }
@@ -49,6 +50,7 @@ __device__ __forceinline__ void nt_epilogue(const vtGemmNT& p, const RowMap& oma
             if (p.round_bf16) v = round_bf16(v);
             if (p.residual) v += p.residual[orow * p.ldr + n + r];
             if (p.rowmod) v += p.rowmod[(int64_t)(m % p.rowmod_period) * p.N + n + r];
+            if (p.out_scale != 0.f) v *= p.out_scale;
             ((float*)p.out)[orow * p.ldo + n + r] = v;
             if (p.out2) ((bf16_t*)p.out2)[orow * p.ldo2 + n + r] = f2bf(v);
         }

@@ -119,6 +119,81 @@ def block_stack(x, blocks, n_head):
     return BlockStack.apply(x, n_head, *block_params(blocks))
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# stack of the TiTok-style gated layers (models/model_new/base/transformer.py:66-91) as one engine call per direction
+# ------------------------------------------------------------------------------------------------------------------------
+PARAMS_PER_GATED_LAYER = 10   # hip.GATED_FIELDS order: to_qkv, q_norm w/b, k_norm w/b, out_proj, ffd LayerNorm w/b, ffd.1, ffd.3
+_GSTACKS = {}
+
+
+def _gstack(key):
+    h = _GSTACKS.get(key)
+    if h is None:
+        cfg = hip.GatedStackConfig(*key)
+        out = ctypes.c_void_p()
+        hip.check(hip.lib().vt_gated_stack_create(ctypes.byref(cfg), ctypes.byref(out)), "vt_gated_stack_create")
+        h = (out, int(hip.lib().vt_gated_stack_workspace_bytes(out)))
+        _GSTACKS[key] = h
+    return h
+
+
+def _gated_array(tensors, depth):
+    arr = (hip.GatedLayerTensors * depth)()
+    for i in range(depth):
+        for j, name in enumerate(hip.GATED_FIELDS):
+            setattr(arr[i], name, tensors[i * PARAMS_PER_GATED_LAYER + j].data_ptr())
+    return arr
+
+
+class GatedStack(torch.autograd.Function):
+    """depth x {x += Attn(x); x += ffd(x); x /= sqrt(i+1)} on x fp32 [B, L, D] (B * L % 64 == 0, D = 64 * heads): ONE
+    vt_gated_stack_forward / _backward call each (11 launches per layer forward, 17 backward, issued by the C++ engine).  The
+    workspace carries the saved activations and the bf16 operand copies of the weights; `pack_key` identifies the weight
+    versions a workspace was packed for."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, n_head, pack_key, *params):
+        hip.require_gpu(x, cos, sin, *params)
+        assert x.dim() == 3
+        B, L, D = x.shape
+        depth = len(params) // PARAMS_PER_GATED_LAYER
+        assert depth * PARAMS_PER_GATED_LAYER == len(params)
+        inner = params[9].shape[1]
+        key = (B, L, D, n_head, depth, inner)
+        handle, nbytes = _gstack(key)
+        params = tuple(p_.detach().float().contiguous() for p_ in params)
+        ws = _take_ws(("gated",) + key, nbytes, x.device)
+        repack = getattr(ws, "_vt_pack_key", None) != pack_key
+        ws._vt_pack_key = pack_key
+        xin = x.contiguous().float()
+        out = torch.empty_like(xin)
+        hip.check(hip.lib().vt_gated_stack_forward(handle, _gated_array(params, depth), hip.ptr(cos), hip.ptr(sin), hip.ptr(xin), hip.ptr(ws), hip.ptr(out),
+                                                   int(repack), hip.stream()), "vt_gated_stack_forward")
+        if any(ctx.needs_input_grad):
+            ctx.key, ctx.ws, ctx.params, ctx.tabs, ctx.done = key, ws, params, (cos, sin), False
+        else:
+            _WS_POOL[(("gated",) + key, str(x.device))].append(ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.done:
+            raise RuntimeError("GatedStack: second backward through the same forward (its workspace was recycled)")
+        B, L, D, H, depth, inner = ctx.key
+        handle, _ = _gstack(ctx.key)
+        grads = [torch.empty_like(p_) for p_ in ctx.params]
+        dx = torch.empty(B, L, D, device=dy.device, dtype=torch.float32)
+        dyc = dy.contiguous().float()
+        cos, sin = ctx.tabs
+        hip.check(hip.lib().vt_gated_stack_backward(handle, _gated_array(ctx.params, depth), hip.ptr(cos), hip.ptr(sin), hip.ptr(dyc), hip.ptr(ctx.ws),
+                                                    _gated_array(grads, depth), hip.ptr(dx), hip.stream()), "vt_gated_stack_backward")
+        ctx.done = True
+        _WS_POOL[(("gated",) + ctx.key, str(dy.device))].append(ctx.ws)
+        ctx.ws = None
+        need = ctx.needs_input_grad[5:]
+        return (dx, None, None, None, None, *[g if n else None for g, n in zip(grads, need)])
+
+
 class PatchEmbed(torch.autograd.Function):
     """PatchEmbed3D.forward (models/embed.py:85-116): Conv3d(kernel = stride = (pt,p,p)) as patch gather + one GEMM,
     bf16-rounded like the conv under autocast, then (optionally) + pos_embed [N, D] in fp32, fused in the epilogue."""

@@ -27,7 +27,7 @@ class GemmNT(ctypes.Structure):
     _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("epi", c_i32), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64), ("bias", c_vp),
                 ("residual", c_vp), ("ldr", c_i64), ("rowmod", c_vp), ("rowmod_period", c_i32), ("aux", c_vp),
-                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp), ("tile", c_i32)]
+                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp), ("out_scale", c_f32), ("tile", c_i32)]
 
 
 class GemmTN(ctypes.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
     "vt_sigmoid_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "vt_geglu_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "vt_geglu_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "vt_scale_rows": (c_i32, [c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp]),
 }
 
 
@@ -104,6 +105,17 @@ class PackJob(ctypes.Structure):
 
 class StackConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("B", "L", "D", "H", "depth")]
+
+
+class GatedStackConfig(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("B", "L", "D", "H", "depth", "inner")]
+
+
+GATED_FIELDS = ("to_qkv_w", "q_norm_w", "q_norm_b", "k_norm_w", "k_norm_b", "out_proj_w", "ln_w", "ln_b", "fc1_w", "fc2_w")
+
+
+class GatedLayerTensors(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in GATED_FIELDS]
 
 
 TENSOR_FIELDS = ("pe_w", "pe_b", "enc_patch_pe", "enc_query", "dec_latent_pe", "dec_patch_query", "dec_token_type", "in_w", "in_b",
@@ -130,6 +142,12 @@ ENGINE_SIGNATURES = {
     "vt_stack_init_workspace": (c_i32, [c_vp, c_vp, c_vp]),
     "vt_stack_forward": (c_i32, [c_vp, ctypes.POINTER(BlockTensors), c_vp, c_vp, c_vp, c_vp]),
     "vt_stack_backward": (c_i32, [c_vp, ctypes.POINTER(BlockTensors), c_vp, c_vp, ctypes.POINTER(BlockTensors), c_vp, c_i32, c_vp]),
+    "vt_gated_stack_create": (c_i32, [ctypes.POINTER(GatedStackConfig), ctypes.POINTER(c_vp)]),
+    "vt_gated_stack_destroy": (None, [c_vp]),
+    "vt_gated_stack_workspace_bytes": (c_sz, [c_vp]),
+    "vt_gated_stack_init_workspace": (c_i32, [c_vp, c_vp, c_vp]),
+    "vt_gated_stack_forward": (c_i32, [c_vp, ctypes.POINTER(GatedLayerTensors), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "vt_gated_stack_backward": (c_i32, [c_vp, ctypes.POINTER(GatedLayerTensors), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GatedLayerTensors), c_vp, c_vp]),
     "vt_tokenizer_create": (c_i32, [ctypes.POINTER(TokenizerConfig), ctypes.POINTER(c_vp)]),
     "vt_tokenizer_destroy": (None, [c_vp]),
     "vt_tokenizer_workspace_bytes": (c_sz, [c_vp]),
@@ -197,7 +215,7 @@ def stream():
 # ---------------------------------------------------------------------------------------------
 
 def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
-            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None):
+            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None, out_scale=0.0):
     """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous)."""
     require_gpu(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
@@ -222,6 +240,7 @@ def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, r
     p.round_bf16 = int(round_bf16)
     p.colsum_partial = colsum_partial.data_ptr() if colsum_partial is not None else None
     p.tile = GEMM_TILE if tile is None else tile
+    p.out_scale = float(out_scale)
     check(lib().vt_gemm_nt(ctypes.byref(p), stream()), "vt_gemm_nt")
     return (out, out2) if epi == EPI_BF16_GELU else out
 

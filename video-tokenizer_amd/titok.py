@@ -16,6 +16,7 @@ backward; torch only owns tensors).  Mixed precision = autocast(bf16) as the ref
 bf16 GEMM operands with fp32 accumulation, fp32 LayerNorm statistics.  GPU tensors only; B * L must be a multiple of 64.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -253,12 +254,23 @@ class ResidualAttentionBlock(nn.Module):
         return hit[1]
 
     def forward(self, x, freqs):
+        """the whole stack as one engine call per direction (functional.GatedStack -> vt_gated_stack_forward / _backward).
+        VT_GATED_PYTHON=1 selects the round-1 composition of one autograd Function per layer instead (A/B and tests)."""
         cos, sin = freqs
+        if os.environ.get("VT_GATED_PYTHON") == "1":
+            for i in range(self.num_layer):
+                at, ff = self.attn_layer[i], self.ffd_layer[i]
+                x = GatedLayer.apply(x, cos, sin, self.heads, 1.0 / math.sqrt(i + 1), self._packs(i), at.to_qkv.weight, at.q_norm.weight, at.q_norm.bias,
+                                     at.k_norm.weight, at.k_norm.bias, at.out_proj.weight, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight)
+            return x
+        from .functional import GatedStack
+        params, key = [], []
         for i in range(self.num_layer):
             at, ff = self.attn_layer[i], self.ffd_layer[i]
-            x = GatedLayer.apply(x, cos, sin, self.heads, 1.0 / math.sqrt(i + 1), self._packs(i), at.to_qkv.weight, at.q_norm.weight, at.q_norm.bias,
-                                 at.k_norm.weight, at.k_norm.bias, at.out_proj.weight, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight)
-        return x
+            params += [at.to_qkv.weight, at.q_norm.weight, at.q_norm.bias, at.k_norm.weight, at.k_norm.bias, at.out_proj.weight, ff[0].weight, ff[0].bias,
+                       ff[1].weight, ff[3].weight]
+            key += [(w.data_ptr(), w._version) for w in (at.to_qkv.weight, at.out_proj.weight, ff[1].weight, ff[3].weight)]
+        return GatedStack.apply(x, cos, sin, self.heads, tuple(key), *params)
 
 
 def init_weights(module):
