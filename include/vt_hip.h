@@ -179,6 +179,11 @@ int vt_unpatchify(const float* rows, int32_t B, int32_t C, int32_t T, int32_t S,
 int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream);
 int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
                      int32_t hd, void* dqkv, float* delta_ws, vtStream stream);
+/* causal variant (head_dim 64): query q attends keys 0..q -- F.scaled_dot_product_attention(..., is_causal=True) inside the AR
+ * consumer's Attention (models/larp_ar.py:186-190) and its autograd.  Same layouts as above. */
+int vt_attention_causal_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, void* o, float* lse2, vtStream stream);
+int vt_attention_causal_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H, void* dqkv,
+                            float* delta_ws, vtStream stream);
 /* The same for the queries q_begin .. L-1 only (q_begin a multiple of 64): `transformer_encoder_parallel` returns
  * h[:, -len(query):] (models/transformer.py:69), so in the LAST block of a stack the other rows' attention outputs are
  * never read and their output gradients are zero.  o / dO are compact [B, L - q_begin, H, hd]; keys/values, lse2,
@@ -270,6 +275,25 @@ int vt_geglu_bwd(const void* da, int64_t lda, const void* h, int64_t M, int32_t 
 /* dst[r, :] = scale * src[r, :] (fp32, may be in place) and/or its bf16 copy: the incoming gradient of a layer whose output was
  * rescaled by 1/sqrt(i+1), produced once for the fp32 residual path and the bf16 GEMM operand.  dim % 4 == 0. */
 int vt_scale_rows(const float* src, float scale, int64_t rows, int32_t dim, float* dst_f32, void* dst_bf16, vtStream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AR consumer (`LARP_AR`, models/larp_ar.py:233-438; consumes the tokenizer's `bottleneck_rep`): the kernels its layers need
+ * beyond vt_gemm_* and vt_attention_causal_*.
+ *   vt_rmsnorm_fwd / _bwd: RMSNorm (models/norm.py:6-17) y = x * rsqrt(mean(x^2) + eps) * w, x fp32 [rows, dim], y bf16, rstd fp32
+ *     [rows] saved; backward adds `dres` (may be NULL), writes dx fp32 and/or bf16 and dw [dim] (fixed-order partial sums in
+ *     `workspace` of vt_rmsnorm_bwd_workspace_bytes(dim)).  dim in {384, 768, 1024, 1280, 1536, 2560} (the llama-abs sizes).
+ *   vt_swiglu_fwd / _bwd: FeedForward (larp_ar.py:122-136) a = silu(w1 x) * (w3 x) on the packed projection h [M, 2I] = [w3 x | w1 x].
+ *   vt_decode_attention: one new token per sequence against the KV cache (larp_ar.py:138-190, `mask = causal_mask[:, None, pos]`):
+ *     q bf16 [B, H, 64], caches bf16 [>=B, H, Lmax, 64], keys 0..n_keys-1 -> o bf16 [B, H, 64].
+ * ------------------------------------------------------------------------------------------ */
+int vt_rmsnorm_fwd(const float* x, const float* w, float eps, int64_t rows, int32_t dim, void* y_bf16, float* rstd, vtStream stream);
+size_t vt_rmsnorm_bwd_workspace_bytes(int32_t dim);
+int vt_rmsnorm_bwd(const void* dy_bf16, const float* x, const float* w, const float* rstd, const float* dres, int64_t rows, int32_t dim,
+                   float* dx, void* dx_bf16, float* dw, void* workspace, vtStream stream);
+int vt_swiglu_fwd(const void* h, int64_t M, int32_t I, void* a, vtStream stream);
+int vt_swiglu_bwd(const void* da, const void* h, int64_t M, int32_t I, void* dh, vtStream stream);
+int vt_decode_attention(const void* q, const void* k_cache, const void* v_cache, int32_t B, int32_t H, int64_t Lmax, int32_t n_keys, void* o,
+                        vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * A stack of those layers as ONE enqueue per direction: `ResidualAttentionBlock.forward` (transformer.py:66-91) and the

@@ -263,16 +263,97 @@ def make_rope(out):
     np.savez_compressed(os.path.join(out, "titok_rope.npz"), **res)
 
 
+def load_reference_ar():
+    """models/larp_ar.py by file path, next to the modules it imports (models.models as `models`, models.embed, models.norm,
+    the `ar` package); huggingface_hub (its PyTorchModelHubMixin base) is installed."""
+    load_reference()
+    _load("models.norm", os.path.join(REF, "models/norm.py"))
+    spec = importlib.util.spec_from_file_location("ar", os.path.join(REF, "ar/__init__.py"), submodule_search_locations=[os.path.join(REF, "ar")])
+    ar = importlib.util.module_from_spec(spec)
+    sys.modules["ar"] = ar
+    spec.loader.exec_module(ar)
+    return _load("models.larp_ar", os.path.join(REF, "models/larp_ar.py"))
+
+
+def ar_cases():
+    # name -> (oracle cfg kwargs, batch, seed)
+    return {"class_S2": (dict(dim=384, n_layer=2, n_head=6, vocab_size=512, max_seq_len=64, num_classes=10), 2, 601),
+            "frame_S2": (dict(dim=384, n_layer=2, n_head=6, vocab_size=256, max_seq_len=48, cls_token_num=16, frame_prediction=True), 2, 602),
+            "class_B1_fixedpe": (dict(dim=768, n_layer=1, n_head=12, vocab_size=320, max_seq_len=32, num_classes=5, use_fixed_pe=True), 4, 603)}
+
+
+def ar_inputs(cfg, B, seed):
+    V, n = cfg["vocab_size"], cfg["max_seq_len"]
+    tok = torch.from_numpy((gen.hash_u64(B * n, seed + 1) % np.uint64(V)).astype(np.int64)).reshape(B, n)
+    if cfg["frame_prediction"]:
+        cond = torch.from_numpy((gen.hash_u64(B * cfg["cls_token_num"], seed + 2) % np.uint64(V)).astype(np.int64)).reshape(B, cfg["cls_token_num"])
+    else:
+        cond = torch.from_numpy((gen.hash_u64(B, seed + 2) % np.uint64(cfg["num_classes"])).astype(np.int64))
+    return tok, cond
+
+
+def make_ar(out):
+    """LARP_AR on the CPU in fp32: training-branch logits / loss / gradients, the `valid` loss, evaluation logits, and
+    greedy generation through the reference's own KV cache (ar/generate.py), with and without classifier-free guidance."""
+    from oracle import ar_oracle
+    ref = load_reference_ar()
+    for name, (kw, B, seed) in ar_cases().items():
+        cfg = ar_oracle.make_cfg(**kw)
+        sd = ar_oracle.init_state_dict(cfg, seed)
+        args = ref.ModelArgs(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"], vocab_size=cfg["vocab_size"], max_seq_len=cfg["max_seq_len"],
+                             num_classes=cfg["num_classes"], cls_token_num=cfg["cls_token_num"], frame_prediction=cfg["frame_prediction"],
+                             use_fixed_pe=cfg["use_fixed_pe"], token_dropout_p=0.0, resid_dropout_p=0.0, ffn_dropout_p=0.0, class_dropout_prob=0.1)
+        m = ref.LARP_AR(args)
+        missing = m.load_state_dict(sd, strict=True)
+        tok, cond = ar_inputs(cfg, B, seed)
+        m.train()
+        if not cfg["frame_prediction"]:
+            m.cls_embedding.dropout_prob = 0.0          # label dropout is random; the fixture is the deterministic part
+        idx = tok[:, :-1]
+        logits, loss = m(idx, cond, targets=tok)
+        loss.backward()
+        grads = {k: v.grad.detach().numpy() for k, v in m.named_parameters() if v.grad is not None}
+        valid = torch.tensor([1.0] + [0.0] * (B - 1))
+        _, loss_valid = m(idx, cond, targets=tok, valid=valid)
+        m.eval()
+        with torch.no_grad():
+            logits_eval, _ = m(idx, cond)
+        res = dict(logits=logits.detach().numpy(), loss=np.float64(loss.item()), loss_valid=np.float64(loss_valid.item()),
+                   logits_eval_sum=checksum(logits_eval.numpy()), logits_eval_shape=np.array(logits_eval.shape),
+                   grad_keys=np.array(sorted(grads)), sd_keys=np.array(sorted(m.state_dict().keys())),
+                   meta=np.array([B, seed], dtype=np.int64))
+        for k, g in grads.items():
+            res["gsum/" + k] = checksum(g)
+        for k in ("norm.weight", "layers.0.attention_norm.weight", "layers.0.ffn_norm.weight"):
+            res["grad/" + k] = grads[k]
+        if "abs_pe" in grads:
+            res["grad/abs_pe"] = grads["abs_pe"]
+        # greedy generation through the KV cache
+        n_new = cfg["max_seq_len"]
+        for scale in ((1.0,) if cfg["frame_prediction"] else (1.0, 3.0)):
+            with m.sampling():
+                seq = ref.ar.generate(m, cond, n_new, cfg_scale=scale, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+            m.reset_caches()
+            res[f"greedy_cfg{scale:g}"] = seq.numpy().astype(np.int32)
+        np.savez_compressed(os.path.join(out, f"ar_{name}.npz"), **res)
+        print("ar", name, "loss", loss.item(), "logits", tuple(logits.shape), "greedy[:8]", res["greedy_cfg1"][0, :8].tolist(), missing)
+    # sampling filter (ar/generate.py:13-52) on a small batch of logits
+    lg = torch.from_numpy(gen.normal((6, 40), 611, 2.0))
+    filt = {f"k{k}_p{pp:g}": sys.modules["ar.generate"].top_k_top_p_filtering(lg.clone(), top_k=k, top_p=pp).numpy() for k, pp in ((0, 0.8), (5, 1.0), (7, 0.6), (0, 0.05))}
+    np.savez_compressed(os.path.join(out, "ar_filtering.npz"), logits=lg.numpy(), **filt)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("fsq", "rope", "sq"):  # only these fixtures (added after the others were committed)
-        {"fsq": make_fsq, "rope": make_rope, "sq": make_sq}[sys.argv[1]](HERE)
+    if len(sys.argv) > 1 and sys.argv[1] in ("fsq", "rope", "sq", "ar"):  # only these fixtures (added after the others were committed)
+        {"fsq": make_fsq, "rope": make_rope, "sq": make_sq, "ar": make_ar}[sys.argv[1]](HERE)
         sys.exit(0)
     models, bott, emb = load_reference()
     make_fsq(HERE)
     make_rope(HERE)
     make_sq(HERE)
+    make_ar(HERE)
     make_vq(models, HERE)
     make_bottleneck(models, HERE)
     make_embed(emb, HERE)

@@ -1,0 +1,70 @@
+"""The LARP_AR restatement (oracle/ar_oracle.py) against outputs of the reference's own LARP_AR, generated on the CPU in the
+build container by tests/golden/make_golden.py::make_ar.  Runs on CPU, never touches /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ar_oracle as A
+from tests.golden.make_golden import ar_cases, ar_inputs, checksum
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _case(name):
+    kw, B, seed = ar_cases()[name]
+    cfg = A.make_cfg(**kw)
+    return cfg, A.init_state_dict(cfg, seed), ar_inputs(cfg, B, seed), np.load(os.path.join(GOLD, f"ar_{name}.npz")), B
+
+
+@pytest.mark.parametrize("name", list(ar_cases()))
+def test_forward_loss_and_gradients_match_reference(name):
+    cfg, sd, (tok, cond), g, B = _case(name)
+    assert sorted(sd.keys()) == g["sd_keys"].tolist()                   # the reference's state-dict layout
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    logits, loss = A.forward(p, cfg, tok[:, :-1], cond, targets=tok)
+    assert logits.shape == g["logits"].shape
+    assert np.abs(logits.detach().numpy() - g["logits"]).max() < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    loss.backward()
+    for k in g["grad_keys"].tolist():
+        gs = g["gsum/" + k]
+        mine = checksum(p[k].grad.numpy())
+        assert np.allclose(mine, gs, rtol=2e-4, atol=2e-6), (k, mine, gs)
+    for k in ("norm.weight", "layers.0.attention_norm.weight", "layers.0.ffn_norm.weight") + (() if cfg["use_fixed_pe"] else ("abs_pe",)):
+        assert np.abs(p[k].grad.numpy() - g["grad/" + k]).max() < 2e-6, k
+    with torch.no_grad():
+        _, lv = A.forward(sd, cfg, tok[:, :-1], cond, targets=tok, valid=torch.tensor([1.0] + [0.0] * (B - 1)))
+        le, _ = A.forward(sd, cfg, tok[:, :-1], cond, training=False)
+    assert abs(lv.item() - float(g["loss_valid"])) < 2e-6
+    assert list(le.shape) == g["logits_eval_shape"].tolist()
+    assert np.allclose(checksum(le.numpy()), g["logits_eval_sum"], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(ar_cases()))
+def test_greedy_generation_matches_reference_kv_cache(name):
+    cfg, sd, (tok, cond), g, B = _case(name)
+    for scale in (1.0,) if cfg["frame_prediction"] else (1.0, 3.0):
+        want = g[f"greedy_cfg{scale:g}"]
+        n_new = 24                                              # a prefix of the reference's full-length generation keeps this fast
+        got, margin = A.generate_greedy(sd, cfg, cond, n_new, cfg_scale=scale, return_margins=True)
+        bad = (got.numpy() != want[:, :n_new])
+        first_bad = [int(np.argmax(r)) if r.any() else n_new for r in bad]
+        for b, fb in enumerate(first_bad):                      # a flip is only tolerated at a top-2 near tie (and ends the comparison)
+            assert fb == n_new or margin[b, fb] < 1e-6, (name, scale, b, fb, float(margin[b, fb]))
+
+
+def test_top_k_top_p_filtering_matches_reference():
+    g = np.load(os.path.join(GOLD, "ar_filtering.npz"))
+    lg = torch.from_numpy(g["logits"])
+    for key, (k, pp) in {"k0_p0.8": (0, 0.8), "k5_p1": (5, 1.0), "k7_p0.6": (7, 0.6), "k0_p0.05": (0, 0.05)}.items():
+        assert np.array_equal(A.top_k_top_p_filtering(lg, top_k=k, top_p=pp).numpy(), g[key]), key
+
+
+def test_bf16_emulation_stays_close_to_fp32():
+    cfg, sd, (tok, cond), g, B = _case("class_S2")
+    with torch.no_grad():
+        le, loss = A.forward(sd, cfg, tok[:, :-1], cond, targets=tok, emu=True)
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    assert np.abs(le.numpy() - g["logits"]).max() < 0.05

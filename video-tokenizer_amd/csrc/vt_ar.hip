@@ -1,0 +1,258 @@
+// Kernels of the AR consumer (`LARP_AR`, /root/reference/models/larp_ar.py:233-438) that the tokenizer path did
+// not already have.  Its matrix products are vt_gemm_nt / vt_gemm_tn_grouped, its training attention vt_attention_causal_*.
+//   rmsnorm       RMSNorm (models/norm.py:6-17): y = x * rsqrt(mean(x^2) + eps) * w, fp32 statistics, bf16 output for the next GEMM
+//   swiglu        FeedForward (larp_ar.py:122-136): silu(w1 x) * (w3 x) on the packed projection h = [w3 x | w1 x]
+//   decode_attn   one new token against the KV cache (larp_ar.py:138-190 with `mask = causal_mask[:, None, input_pos]`): a GEMV-sized
+//                 softmax(q K^T / 8) V per (batch, head), memory-bound, one wave per (b, h)
+// All HBM-bound single passes, 8- or 16-byte accesses, rounding points of autocast(bf16).
+#include "vt_common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    const float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------------------------- RMSNorm
+// one wave per row; lane l owns the float2 pieces (j * 64 + l), j < J = dim / 128: every load instruction of the wave is a
+// contiguous 512-byte run.  J in {3, 6, 8, 10, 12, 20} <=> dim in {384, 768, 1024, 1280, 1536, 2560} (every llama-abs size).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int J>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float eps, int64_t rows,
+                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
+    constexpr int dim = J * 128;
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const f32x2* xr = (const f32x2*)(x + r * dim);
+        f32x2 v[J];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            v[j] = xr[j * 64 + lane];
+            ss = fmaf(v[j][0], v[j][0], ss);
+            ss = fmaf(v[j][1], v[j][1], ss);
+        }
+        ss = wave_sum(ss);
+        const float rstd = __builtin_amdgcn_rsqf(ss * (1.0f / dim) + eps);
+        if (lane == 0 && rstd_out) rstd_out[r] = rstd;
+        bf16x2* yr = (bf16x2*)(y + r * dim);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x2 ww = ((const f32x2*)w)[j * 64 + lane];
+            yr[j * 64 + lane] = (bf16x2){f2bf(v[j][0] * rstd * ww[0]), f2bf(v[j][1] * rstd * ww[1])};
+        }
+    }
+}
+
+// dx = rstd * g - x * rstd^3 / dim * sum(x * g) (+ dres), g = w * dy; per-block partial sums of dw = sum_rows dy * x * rstd
+template <int J>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t rows,
+                                                           float* __restrict__ dx, bf16_t* __restrict__ dxb, float* __restrict__ dw_part) {
+    constexpr int dim = J * 128;
+    __shared__ float red[4][dim];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    f32x2 dwacc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) dwacc[j] = (f32x2){0.f, 0.f};
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += (int64_t)gridDim.x * 4) {
+        const f32x2* xr = (const f32x2*)(x + r * dim);
+        const bf16x2* dyr = (const bf16x2*)(dy + r * dim);
+        const float rstd = rstd_in[r];
+        f32x2 xv[J], g[J];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            xv[j] = xr[j * 64 + lane];
+            const bf16x2 d = dyr[j * 64 + lane];
+            const f32x2 ww = ((const f32x2*)w)[j * 64 + lane];
+            const f32x2 dyf = {bf2f(d[0]), bf2f(d[1])};
+            g[j] = dyf * ww;
+            dot = fmaf(xv[j][0], g[j][0], dot);
+            dot = fmaf(xv[j][1], g[j][1], dot);
+            dwacc[j] += dyf * xv[j] * rstd;
+        }
+        dot = wave_sum(dot);
+        const float k = dot * rstd * rstd * rstd * (1.0f / dim);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            f32x2 o = g[j] * rstd - xv[j] * k;
+            if (dres) o += ((const f32x2*)(dres + r * dim))[j * 64 + lane];
+            if (dx) ((f32x2*)(dx + r * dim))[j * 64 + lane] = o;
+            if (dxb) ((bf16x2*)(dxb + r * dim))[j * 64 + lane] = (bf16x2){f2bf(o[0]), f2bf(o[1])};
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) ((f32x2*)red[wv])[j * 64 + lane] = dwacc[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < dim; c += 256) dw_part[(int64_t)blockIdx.x * dim + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+constexpr int RMS_BLOCKS = 256;   // partial-sum rows of the weight gradient (fixed: the reduction order does not depend on the row count)
+
+// ---------------------------------------------------------------------------------------------------- SwiGLU
+struct V8 {
+    float v[8];
+};
+__device__ __forceinline__ V8 ld8(const bf16_t* p) {
+    const bf16x8 r = *(const bf16x8*)p;
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = bf2f(r[i]);
+    return o;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const V8& a) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = f2bf(a.v[i]);
+    *(bf16x8*)p = r;
+}
+
+// h [M, 2I] = [w3 x | w1 x]; a = silu(h[:, I:]) * h[:, :I]
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ h, int64_t M, int I, bf16_t* __restrict__ a) {
+    const int64_t per_row = I / 8, total = M * per_row;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+        const int64_t row = u / per_row;
+        const int col = (int)(u % per_row) * 8;
+        const V8 x = ld8(h + row * 2 * I + col), g = ld8(h + row * 2 * I + I + col);
+        V8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = round_bf16(silu_f(g.v[i])) * x.v[i];
+        st8(a + row * I + col, r);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ h, int64_t M, int I, bf16_t* __restrict__ dh) {
+    const int64_t per_row = I / 8, total = M * per_row;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+        const int64_t row = u / per_row;
+        const int col = (int)(u % per_row) * 8;
+        const V8 dy = ld8(da + row * I + col), x = ld8(h + row * 2 * I + col), g = ld8(h + row * 2 * I + I + col);
+        V8 dx, dg;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dx.v[i] = dy.v[i] * round_bf16(silu_f(g.v[i]));
+            dg.v[i] = round_bf16(dy.v[i] * x.v[i]) * silu_grad_f(g.v[i]);
+        }
+        st8(dh + row * 2 * I + col, dx);
+        st8(dh + row * 2 * I + I + col, dg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- decode attention (KV cache)
+// q [B, H, 64] bf16 (the new token), caches k, v [Bmax, H, Lmax, 64] bf16 (larp_ar.py:138-151), keys 0..n_keys-1 visible.
+// One wave per (b, h): lane l scores keys l, l + 64, ...; softmax over the wave; then every lane owns ONE output dimension
+// (lane = d) and walks the keys with the probabilities broadcast through LDS.
+__global__ __launch_bounds__(64) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc, int H,
+                                                          int64_t Lmax, int n_keys, bf16_t* __restrict__ o) {
+    extern __shared__ float probs[];            // [n_keys rounded up to 64]
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const bf16_t* qp = q + ((int64_t)b * H + h) * 64;
+    const bf16_t* kp = kc + ((int64_t)b * H + h) * Lmax * 64;
+    const bf16_t* vp = vc + ((int64_t)b * H + h) * Lmax * 64;
+    float qv[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 t = *(const bf16x8*)(qp + 8 * c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[8 * c + i] = bf2f(t[i]);
+    }
+    float mx = -__builtin_inff();
+    for (int k0 = 0; k0 < n_keys; k0 += 64) {
+        const int key = k0 + lane;
+        float s = -__builtin_inff();
+        if (key < n_keys) {
+            s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 t = *(const bf16x8*)(kp + (int64_t)key * 64 + 8 * c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(qv[8 * c + i], bf2f(t[i]), s);
+            }
+            s *= 0.125f;
+        }
+        probs[key] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int k0 = 0; k0 < n_keys; k0 += 64) {
+        const float p = __expf(probs[k0 + lane] - mx);     // exp(-inf) = 0 for the padded keys
+        probs[k0 + lane] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float acc = 0.f;
+    for (int key = 0; key < n_keys; ++key) acc = fmaf(round_bf16(probs[key] / sum), bf2f(vp[(int64_t)key * 64 + lane]), acc);
+    o[((int64_t)b * H + h) * 64 + lane] = f2bf(acc);
+}
+
+int grid_for(int64_t units) {
+    const int64_t b = (units + 255) / 256;
+    return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);
+}
+}  // namespace
+
+#define RMS_DISPATCH(KERNEL, ...)                                                              \
+    switch (dim / 128) {                                                                       \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                             \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                             \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                             \
+        case 10: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                           \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, __VA_ARGS__); break;                           \
+        default: hipLaunchKernelGGL(KERNEL<20>, __VA_ARGS__); break;                           \
+    }
+
+static bool rms_dim_ok(int dim) { return dim == 384 || dim == 768 || dim == 1024 || dim == 1280 || dim == 1536 || dim == 2560; }
+
+extern "C" int vt_rmsnorm_fwd(const float* x, const float* w, float eps, int64_t rows, int32_t dim, void* y_bf16, float* rstd, vtStream stream) {
+    VT_CHECK_ARG(x && w && y_bf16 && rows > 0, "vt_rmsnorm_fwd: null pointer");
+    VT_CHECK_ARG(rms_dim_ok(dim), "vt_rmsnorm_fwd: width %d unsupported (384, 768, 1024, 1280, 1536, 2560: the llama-abs sizes)", dim);
+    const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    RMS_DISPATCH(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, eps, rows, (bf16_t*)y_bf16, rstd)
+    VT_CHECK_LAUNCH("vt_rmsnorm_fwd");
+    return VT_OK;
+}
+
+extern "C" size_t vt_rmsnorm_bwd_workspace_bytes(int32_t dim) { return (size_t)RMS_BLOCKS * dim * sizeof(float); }
+
+extern "C" int vt_rmsnorm_bwd(const void* dy_bf16, const float* x, const float* w, const float* rstd, const float* dres, int64_t rows, int32_t dim,
+                              float* dx, void* dx_bf16, float* dw, void* workspace, vtStream stream) {
+    VT_CHECK_ARG(dy_bf16 && x && w && rstd && (dx || dx_bf16) && dw && workspace && rows > 0, "vt_rmsnorm_bwd: null pointer");
+    VT_CHECK_ARG(rms_dim_ok(dim), "vt_rmsnorm_bwd: width %d unsupported", dim);
+    float* part = (float*)workspace;
+    RMS_DISPATCH(rmsnorm_bwd_kernel, dim3(RMS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy_bf16, x, w, rstd, dres, rows, dx, (bf16_t*)dx_bf16, part)
+    VT_CHECK_LAUNCH("vt_rmsnorm_bwd");
+    return vt_sum_slabs(part, RMS_BLOCKS, (int64_t)dim, dim, dw, stream);
+}
+
+extern "C" int vt_swiglu_fwd(const void* h, int64_t M, int32_t I, void* a, vtStream stream) {
+    VT_CHECK_ARG(h && a && M > 0 && I > 0 && I % 8 == 0, "vt_swiglu_fwd: null pointer or I %% 8 != 0");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(M * (I / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, M, I, (bf16_t*)a);
+    VT_CHECK_LAUNCH("vt_swiglu_fwd");
+    return VT_OK;
+}
+
+extern "C" int vt_swiglu_bwd(const void* da, const void* h, int64_t M, int32_t I, void* dh, vtStream stream) {
+    VT_CHECK_ARG(da && h && dh && M > 0 && I > 0 && I % 8 == 0, "vt_swiglu_bwd: null pointer or I %% 8 != 0");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * (I / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, (const bf16_t*)h, M, I, (bf16_t*)dh);
+    VT_CHECK_LAUNCH("vt_swiglu_bwd");
+    return VT_OK;
+}
+
+extern "C" int vt_decode_attention(const void* q, const void* k_cache, const void* v_cache, int32_t B, int32_t H, int64_t Lmax, int32_t n_keys, void* o,
+                                   vtStream stream) {
+    VT_CHECK_ARG(q && k_cache && v_cache && o && B > 0 && H > 0 && n_keys > 0 && n_keys <= Lmax, "vt_decode_attention: bad arguments (1 <= n_keys <= Lmax)");
+    VT_CHECK_ARG(n_keys <= 16384, "vt_decode_attention: n_keys %d > 16384", n_keys);
+    const size_t lds = (size_t)((n_keys + 63) / 64 * 64) * sizeof(float);
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(B * H), dim3(64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, H,
+                       Lmax, n_keys, (bf16_t*)o);
+    VT_CHECK_LAUNCH("vt_decode_attention");
+    return VT_OK;
+}

@@ -209,8 +209,11 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
+// CAUSAL (the AR consumer, models/larp_ar.py:186-190 `is_causal=True`): query q attends keys 0..q.  A workgroup stops at the last
+// tile its 128 queries can see; per wave a tile is plain (every key <= every query of the wave), masked (fwd_tile<TAIL> with
+// the per-lane limit q + 1 in place of L) or skipped.
+template <int HD, bool CAUSAL = false>
+__global__ __launch_bounds__(256, CAUSAL ? 3 : 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
                                                            int L, int H, int nblk, float scale_log2e, int q_begin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -255,6 +258,30 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     const int nfull = (L & 63) ? nt - 1 : nt;
     unsigned soff[AG<HD>::CH / 4];
     stage_offsets<HD>(rs, tid, soff);
+    if constexpr (CAUSAL) {
+        const int q_end = min(L, q_begin + blk * 128 + 128);            // one past the workgroup's last query
+        const int nt_c = min(nt, (q_end + 63) / 64);                    // tiles any of its queries can see
+        const int nvis = min(nfull, (q0 + 1) / 64);                     // tiles with every key <= the wave's first query
+        const int lim = min(L, q0 + (lane & 31) + 1);                   // this lane's query sees keys < lim
+        for (int t = 0; t < nt_c; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt_c) {
+                if (t + 1 < nfull) {
+                    const bf16_t* kt = kb + (int64_t)(t + 1) * 64 * rs;
+                    stage64_full<HD>(kt, soff, sbase + (cur ^ 1) * 2 * TILE, wave);
+                    stage64_full<HD>(kt + (int64_t)H * HD, soff, sbase + (cur ^ 1) * 2 * TILE + TILE, wave);
+                } else {
+                    stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
+                    stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+                }
+            }
+            const char* kl = smem + cur * 2 * TILE;
+            if (t < nvis) fwd_tile<HD, false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
+            else if (t * 64 <= q0 + 31) fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, lim, scale_log2e, lane, half);
+            dma_drain();
+            __syncthreads();
+        }
+    } else {
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nfull) {          // next tile is a full one: scalar base + invariant lane offsets
@@ -273,6 +300,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     if (nfull < nt) {
         const char* kl = smem + (nfull & 1) * 2 * TILE;
         fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane, half);
+    }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const int q = q0 + (lane & 31);
@@ -647,8 +675,8 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d] for its own rows (both operands are one 16-B load per k-step away) and
 // leaves it in `delta` for the dK/dV kernel, which is launched behind this one.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+template <int HD, bool CAUSAL = false>
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ dO, const float* __restrict__ lse2,
                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, int H, int nblk,
                                                               float scale, float scale_log2e, int q_begin) {
@@ -707,6 +735,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
     const int nfull = (L & 63) ? nt - 1 : nt;
     unsigned soff[AG<HD>::CH / 4];
     stage_offsets<HD>(rs, tid, soff);
+    if constexpr (CAUSAL) {   // see attn_fwd_kernel
+        const int q_end = min(L, q_begin + blk * 128 + 128);
+        const int nt_c = min(nt, (q_end + 63) / 64);
+        const int nvis = min(nfull, (q0 + 1) / 64);
+        const int lim = min(L, q0 + (lane & 31) + 1);
+        for (int t = 0; t < nt_c; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt_c) {
+                if (t + 1 < nfull) {
+                    const bf16_t* kt = kb + (int64_t)(t + 1) * 64 * rs;
+                    stage64_full<HD>(kt, soff, sbase + (cur ^ 1) * 2 * TILE, wave);
+                    stage64_full<HD>(kt + (int64_t)H * HD, soff, sbase + (cur ^ 1) * 2 * TILE + TILE, wave);
+                } else {
+                    stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
+                    stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
+                }
+            }
+            const char* kl = smem + cur * 2 * TILE;
+            if (t < nvis) dq_tile<HD, false>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, t * 64, L, scale_log2e, lane, half);
+            else if (t * 64 <= q0 + 31) dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, t * 64, lim, scale_log2e, lane, half);
+            dma_drain();
+            __syncthreads();
+        }
+    } else {
     for (int t = 0; t < nfull; ++t) {
         const int cur = t & 1;
         if (t + 1 < nfull) {
@@ -726,13 +778,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
         const char* kl = smem + (nfull & 1) * 2 * TILE;
         dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, nfull * 64, L, scale_log2e, lane, half);
     }
+    }
     store_own<DT>(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
 }
 
 // one 64-query tile of the dK/dV sweep.  LDS buffer: Q tile | dO tile | lse2[64] | delta[64]
-template <int HD, bool TAIL>
+template <int HD, bool TAIL, bool CAUSAL = false>
 __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD / 16], const bf16x8 (&vf)[HD / 16], f32x16 (&dk)[HD / 32],
-                                         f32x16 (&dv)[HD / 32], int q0, int L, float c, int lane, int half) {
+                                         f32x16 (&dv)[HD / 32], int q0, int L, float c, int lane, int half, int my_key = 0) {
     constexpr int TILE = AG<HD>::TILE;
     const char* do_l = qt_l + TILE;
     const float* lse_l = (const float*)(qt_l + 2 * TILE);
@@ -757,6 +810,7 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD
                 const int r = 4 * g + e;
                 float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse4[e]));
                 if (TAIL && (q0 + qt * 32 + reg_row(r, half) >= L)) p = 0.f;
+                if (CAUSAL && (q0 + qt * 32 + reg_row(r, half) < my_key)) p = 0.f;     // a query never attends a later key
                 sacc[r] = p;
                 dp[r] = p * (dp[r] - del4[e]);
             }
@@ -777,7 +831,7 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD
 // ------------------------------------------------------------------------------------------------
 // dK, dV: own rows = keys; streams Q and dO tiles (both row reads and transposed reads) + lse2/delta
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool CAUSAL = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e,
@@ -835,7 +889,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             glds4_asm((wave == 0 ? lse_b : del_b) + qq, base + 2 * TILE + wave * 256);
         }
     };
-    const int t0 = q_begin >> 6;
+    // CAUSAL: query tiles before the workgroup's first key contribute nothing (every query < every key)
+    const int t0 = CAUSAL ? max(q_begin >> 6, (blk * 128) >> 6) : q_begin >> 6;
     stage(t0, 0);
     pin_loaded(kf);
     pin_loaded(vf);
@@ -843,6 +898,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     __syncthreads();
 
     const int nfull = (L & 63) ? nt - 1 : nt;
+    if constexpr (CAUSAL) {
+        for (int t = t0; t < nt; ++t) {
+            const int cur = (t - t0) & 1;
+            if (t + 1 < nt) stage(t + 1, cur ^ 1);
+            if (t < nfull && t * 64 >= k0 + 31) dkv_tile<HD, false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
+            else if (t * 64 + 63 >= k0) dkv_tile<HD, true, true>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half, key);
+            dma_drain();
+            __syncthreads();
+        }
+    } else {
     for (int t = t0; t < nfull; ++t) {
         const int cur = (t - t0) & 1;
         if (t + 1 < nt) stage(t + 1, cur ^ 1);
@@ -851,6 +916,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         __syncthreads();
     }
     if (nfull < nt) dkv_tile<HD, true>(smem + ((nfull - t0) & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
+    }
     bf16_t* dkb = dqkv + (int64_t)b * L * rs + (int64_t)h * HD + (int64_t)H * HD;
     store_own<DT>(dk, scale, dkb, rs, key, key < L, half);
     store_own<DT>(dv, 1.0f, dkb + (int64_t)H * HD, rs, key, key < L, half);
@@ -955,4 +1021,35 @@ extern "C" int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H
 extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,
                                 int32_t hd, void* dqkv, float* delta_ws, vtStream stream) {
     return vt_attention_bwd_rows(qkv, o, dO, lse2, B, L, H, hd, 0, dqkv, delta_ws, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// causal attention (the AR consumer): F.scaled_dot_product_attention(q, k, v, is_causal=True) of
+// /root/reference/models/larp_ar.py:186-190 and its autograd; head_dim 64 (every llama-abs size: dim / n_head = 64)
+// ------------------------------------------------------------------------------------------------
+extern "C" int vt_attention_causal_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, void* o, float* lse2, vtStream stream) {
+    VT_CHECK_ARG(qkv && o && lse2, "vt_attention_causal_fwd: null pointer");
+    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_causal_fwd: bad shape");
+    const float sl2 = 0.125f * 1.44269504088896340736f;
+    const int nblk = (L + 127) / 128;
+    hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(nblk * B * H), dim3(256), 4 * AG<64>::TILE, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H,
+                       nblk, sl2, 0);
+    VT_CHECK_LAUNCH("vt_attention_causal_fwd");
+    return VT_OK;
+}
+
+extern "C" int vt_attention_causal_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H, void* dqkv,
+                                       float* delta_ws, vtStream stream) {
+    VT_CHECK_ARG(qkv && o && dO && lse2 && dqkv && delta_ws, "vt_attention_causal_bwd: null pointer");
+    VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_causal_bwd: bad shape");
+    const float scale = 0.125f, sl2 = scale * 1.44269504088896340736f;
+    const int nblk = (L + 127) / 128;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), dim3(nblk * B * H), dim3(256), 4 * AG<64>::TILE, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dO,
+                       lse2, delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2, 0);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), dim3(nblk * B * H), dim3(256), 2 * (2 * AG<64>::TILE + 512), s, (const bf16_t*)qkv, (const bf16_t*)dO, lse2,
+                       delta_ws, (bf16_t*)dqkv, L, H, nblk, scale, sl2, 0);
+    VT_CHECK_LAUNCH("vt_attention_causal_bwd");
+    return VT_OK;
 }

@@ -62,6 +62,8 @@ SIGNATURES = {
     "vt_unpatchify": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vt_attention_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_attention_causal_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_attention_causal_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_fwd_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
@@ -84,6 +86,12 @@ SIGNATURES = {
     "vt_geglu_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "vt_geglu_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "vt_scale_rows": (c_i32, [c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "vt_rmsnorm_fwd": (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "vt_rmsnorm_bwd_workspace_bytes": (c_sz, [c_i32]),
+    "vt_rmsnorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vt_swiglu_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "vt_swiglu_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "vt_decode_attention": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
 }
 
 
@@ -360,6 +368,67 @@ def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0):
     delta = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32)
     check(lib().vt_attention_bwd_rows(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
     return dqkv
+
+
+def attention_causal_fwd(qkv, B, L, H):
+    """F.scaled_dot_product_attention(q, k, v, is_causal=True) on the packed projection [B * L, 3 * H * 64]"""
+    o = torch.empty(B * L, H * 64, device=qkv.device, dtype=torch.bfloat16)
+    lse2 = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
+    check(lib().vt_attention_causal_fwd(ptr(qkv), B, L, H, ptr(o), ptr(lse2), stream()), "vt_attention_causal_fwd")
+    return o, lse2
+
+
+def attention_causal_bwd(qkv, o, dO, lse2, B, L, H):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32)
+    check(lib().vt_attention_causal_bwd(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, ptr(dqkv), ptr(delta), stream()), "vt_attention_causal_bwd")
+    return dqkv
+
+
+def rmsnorm_fwd(x, w, eps):
+    require_gpu(x, w)
+    rows, dim = x.shape
+    y = torch.empty(rows, dim, device=x.device, dtype=torch.bfloat16)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib().vt_rmsnorm_fwd(ptr(x), ptr(w), eps, rows, dim, ptr(y), ptr(rstd), stream()), "vt_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, want_bf16=False):
+    require_gpu(dy, x, w, rstd)
+    rows, dim = x.shape
+    dx = torch.empty_like(x)
+    dxb = torch.empty(rows, dim, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    dw = torch.empty(dim, device=x.device, dtype=torch.float32)
+    ws = _ws(lib().vt_rmsnorm_bwd_workspace_bytes(dim), x.device)
+    check(lib().vt_rmsnorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(dres), rows, dim, ptr(dx), ptr(dxb), ptr(dw), ptr(ws), stream()), "vt_rmsnorm_bwd")
+    return dx, dxb, dw
+
+
+def swiglu_fwd(h):
+    require_gpu(h)
+    M, I2 = h.shape
+    a = torch.empty(M, I2 // 2, device=h.device, dtype=torch.bfloat16)
+    check(lib().vt_swiglu_fwd(ptr(h), M, I2 // 2, ptr(a), stream()), "vt_swiglu_fwd")
+    return a
+
+
+def swiglu_bwd(da, h):
+    require_gpu(da, h)
+    M, I2 = h.shape
+    dh = torch.empty_like(h)
+    check(lib().vt_swiglu_bwd(ptr(da), ptr(h), M, I2 // 2, ptr(dh), stream()), "vt_swiglu_bwd")
+    return dh
+
+
+def decode_attention(q, k_cache, v_cache, n_keys):
+    """q bf16 [B, H, 64]; caches bf16 [Bmax, H, Lmax, 64] (contiguous); keys 0..n_keys-1 visible -> o bf16 [B, H, 64]"""
+    require_gpu(q, k_cache, v_cache)
+    B, H, _ = q.shape
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[1] == H and k_cache.shape[3] == 64 and k_cache.shape[0] >= B
+    o = torch.empty_like(q)
+    check(lib().vt_decode_attention(ptr(q), ptr(k_cache), ptr(v_cache), B, H, k_cache.shape[2], n_keys, ptr(o), stream()), "vt_decode_attention")
+    return o
 
 
 def vq_forward(z_in, codebook, mode, l2_normalized=True, inv_tau=1.0, beta=0.25, codebook_w=1.0, seed=0, ldp=0):
