@@ -285,6 +285,10 @@ int vt_scale_rows(const float* src, float scale, int64_t rows, int32_t dim, floa
  *   vt_swiglu_fwd / _bwd: FeedForward (larp_ar.py:122-136) a = silu(w1 x) * (w3 x) on the packed projection h [M, 2I] = [w3 x | w1 x].
  *   vt_decode_attention: one new token per sequence against the KV cache (larp_ar.py:138-190, `mask = causal_mask[:, None, pos]`):
  *     q bf16 [B, H, 64], caches bf16 [>=B, H, Lmax, 64], keys 0..n_keys-1 -> o bf16 [B, H, 64].
+ *   vt_decode_attention_step: the same for the generation loop (ar/generate.py:99-123) without a host round trip: `pos_dev` (device
+ *     int32: the new token's position = number of earlier keys) is read by the kernel, the new token's k / v are taken from the
+ *     packed projection row qkv [B, 3 * H * 64] = [q | k | v], stored into the caches at `pos` (KVCache.update, larp_ar.py:153-161)
+ *     and attended together with keys 0..pos-1.  With it one decode step has no host-side dependency and can be replayed as a hipGraph.
  * ------------------------------------------------------------------------------------------ */
 int vt_rmsnorm_fwd(const float* x, const float* w, float eps, int64_t rows, int32_t dim, void* y_bf16, float* rstd, vtStream stream);
 size_t vt_rmsnorm_bwd_workspace_bytes(int32_t dim);
@@ -294,6 +298,8 @@ int vt_swiglu_fwd(const void* h, int64_t M, int32_t I, void* a, vtStream stream)
 int vt_swiglu_bwd(const void* da, const void* h, int64_t M, int32_t I, void* dh, vtStream stream);
 int vt_decode_attention(const void* q, const void* k_cache, const void* v_cache, int32_t B, int32_t H, int64_t Lmax, int32_t n_keys, void* o,
                         vtStream stream);
+int vt_decode_attention_step(const void* qkv, void* k_cache, void* v_cache, int32_t B, int32_t H, int64_t Lmax, const int32_t* pos_dev, void* o,
+                             vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * A stack of those layers as ONE enqueue per direction: `ResidualAttentionBlock.forward` (transformer.py:66-91) and the

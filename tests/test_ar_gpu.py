@@ -136,6 +136,27 @@ def test_decode_attention_vs_torch(n_keys):
         hip.decode_attention(q, kc, vc, Lmax + 1)
 
 
+@pytest.mark.parametrize("pos", [0, 1, 7, 8, 63, 500, 1031])
+def test_decode_attention_step_updates_cache_and_matches_torch(pos):
+    """the graph-capturable decode step: position read from device memory, k / v of the new token stored into the caches"""
+    from video_tokenizer_amd import hip
+    B, Bmax, H, Lmax = 3, 4, 6, 1032
+    D = H * 64
+    qkv = torch.from_numpy(gen.normal((B, 3 * D), 61, 1.2)).cuda().to(torch.bfloat16)
+    kc = torch.from_numpy(gen.normal((Bmax, H, Lmax, 64), 62)).cuda().to(torch.bfloat16)
+    vc = torch.from_numpy(gen.normal((Bmax, H, Lmax, 64), 63)).cuda().to(torch.bfloat16)
+    k0, v0 = kc.clone(), vc.clone()
+    o = hip.decode_attention_step(qkv, kc, vc, torch.tensor([pos], device="cuda", dtype=torch.int32))
+    q, k, v = (t.reshape(B, H, 64) for t in qkv.split(D, dim=-1))
+    k0[:B, :, pos], v0[:B, :, pos] = k, v
+    assert torch.equal(kc, k0) and torch.equal(vc, v0)                          # exactly one row per (b, h) changed, to the new k / v
+    s = torch.einsum("bhd,bhkd->bhk", q.float(), k0[:B, :, :pos + 1].float()) / 8.0
+    ref = torch.einsum("bhk,bhkd->bhd", torch.softmax(s, -1), v0[:B, :, :pos + 1].float()).reshape(B, D)
+    assert rel(o, ref) < 4e-3, rel(o, ref)
+    o2 = hip.decode_attention(q.contiguous(), kc, vc, pos + 1)                  # same kernel body, position by value, keys from the cache
+    assert torch.equal(o2.reshape(B, D), o)
+
+
 # ------------------------------------------------------------------------------------------------ the module
 def build(name, **over):
     import video_tokenizer_amd as vt
@@ -207,6 +228,25 @@ def test_greedy_generation_through_kv_cache_matches_reference(name):
             assert diff.size == 0 or margin[b, diff[0]] < 2e-3, (name, scale, b, diff[:4], float(margin[b, diff[0]]))
         agree = (got == g[f"greedy_cfg{scale:g}"]).mean()
         print(name, "cfg", scale, "agreement with the reference's fp32 generation:", agree)
+
+
+def test_graph_replayed_generation_equals_eager_loop():
+    """the hipGraph-captured decode step replays the same kernels on the same buffers: greedy tokens are identical to the eager loop's"""
+    from video_tokenizer_amd.larp_ar import generate
+    m, cfg, sd, (tok, cond), B = build("class_S2")
+    m.eval()
+    outs = []
+    for use_graph in (False, True):
+        with m.sampling():
+            outs.append(generate(m, cond.cuda(), cfg["max_seq_len"], cfg_scale=3.0, cfg_interval=20, use_graph=use_graph, temperature=1.0, top_k=0, top_p=1.0,
+                                 sample_logits=False))
+        m.reset_caches()
+    assert torch.equal(outs[0], outs[1])
+    torch.manual_seed(3)
+    with m.sampling():                                                          # sampled path (top-k / top-p / multinomial inside the graph): valid tokens
+        s = generate(m, cond.cuda(), cfg["max_seq_len"], cfg_scale=1.0, use_graph=True, temperature=0.8, top_k=40, top_p=0.9, sample_logits=True)
+    m.reset_caches()
+    assert int(s.min()) >= 0 and int(s.max()) < cfg["vocab_size"]
 
 
 def test_cached_decode_equals_full_recomputation():

@@ -382,7 +382,7 @@ def test_fused_adam_skips_frozen_parameters_like_torch_adam():
             assert torch.allclose(ema[n], before[n], rtol=1e-6, atol=1e-7), n        # EMA of an unchanged weight stays there
         else:
             assert not torch.equal(p.detach(), before[n]), n
-            assert rel(p.detach().cpu(), ref_params[n].detach().cpu()) < 1e-5, n
+            assert rel(p.detach().cpu(), ref_params[n].detach().cpu()) < 5e-5, n     # two steps: the 2nd sees weights that differ by an ulp
 
 
 def test_backward_into_existing_grads_and_autograd_grad():

@@ -29,6 +29,11 @@ def _rand(shape, seed, std=1.0):
     return gen.normal(shape, seed, std)
 
 
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.fixture(params=[1, 2, 5, 6], ids=["tile128", "tile192", "tile192x96", "tile192_one_tile_per_wg"], autouse=False)
 def gemm_variant(request, hip):
@@ -100,6 +105,33 @@ def test_gemm_nt_f32_residual_rowmod_rowmap(hip, gemm_variant):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
     assert torch.equal(got[:off], out[:off])  # untouched rows stay untouched
     np.testing.assert_allclose(out2.float().cpu().numpy()[off:off + n], ref.to(torch.bfloat16).float().numpy()[off:off + n], rtol=1e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64])
+@pytest.mark.parametrize("N,K", [(16, 64), (100, 384), (768, 2048), (2304, 768), (8192, 1280)])
+def test_gemm_nt_skinny_matches_tile_kernel_and_torch(hip, M, N, K):
+    """M <= 64 dispatches to the weight-streaming kernel (tile 7): every epilogue against the 128-row tile kernel and fp32 torch"""
+    A, B = bf(_rand((M, K), 81 + M, 0.5)).cuda(), bf(_rand((N, K), 82 + N, 0.5)).cuda()
+    ref = A.float() @ B.float().t()
+    Np = (N + 3) // 4 * 4
+    bias = torch.from_numpy(_rand((N,), 83, 0.2)).cuda()
+    res = torch.from_numpy(_rand((M, Np), 84)).cuda()
+    # integers: exact, any summation order
+    Ai = torch.from_numpy((np.arange(M * K).reshape(M, K) % 5 - 2).astype(np.float32)).to(torch.bfloat16).cuda()
+    Bi = torch.from_numpy((np.arange(N * K).reshape(N, K) % 7 - 3).astype(np.float32)).to(torch.bfloat16).cuda()
+    assert torch.equal(hip.gemm_nt(Ai, Bi, hip.EPI_F32, out=torch.empty(M, Np, device="cuda"), tile=7)[:, :N], Ai.float() @ Bi.float().t())
+    for tile in (0, 7):     # 0 = automatic: must pick the same kernel
+        o_bf = hip.gemm_nt(A, B, hip.EPI_BF16, bias=bias, out=torch.empty(M, Np, device="cuda", dtype=torch.bfloat16), tile=tile)[:, :N]
+        o_f = hip.gemm_nt(A, B, hip.EPI_F32, out=torch.full((M, Np), 3.0, device="cuda"), residual=res, round_bf16=True, tile=tile)
+        assert rel(o_bf, (ref + bias).to(torch.bfloat16)) < 4e-3
+        assert rel(o_f[:, :N], ref.to(torch.bfloat16).float() + res[:, :N]) < 2e-3
+        assert torch.equal(o_f[:, N:], torch.full((M, Np - N), 3.0, device="cuda"))          # pad columns untouched
+    t_bf = hip.gemm_nt(A, B, hip.EPI_BF16, bias=bias, out=torch.empty(M, Np, device="cuda", dtype=torch.bfloat16), tile=1)[:, :N]
+    assert rel(o_bf, t_bf) < 3e-3
+    if N % 4 == 0:
+        u, g = hip.gemm_nt(A, B, hip.EPI_BF16_GELU, bias=bias, tile=7)
+        u1, g1 = hip.gemm_nt(A, B, hip.EPI_BF16_GELU, bias=bias, tile=1)
+        assert rel(u, u1) < 3e-3 and rel(g, g1) < 4e-3
 
 
 def test_gemm_tn_grouped(hip, gemm_variant):

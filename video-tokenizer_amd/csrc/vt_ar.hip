@@ -143,54 +143,122 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------- decode attention (KV cache)
-// q [B, H, 64] bf16 (the new token), caches k, v [Bmax, H, Lmax, 64] bf16 (larp_ar.py:138-151), keys 0..n_keys-1 visible.
-// One wave per (b, h): lane l scores keys l, l + 64, ...; softmax over the wave; then every lane owns ONE output dimension
-// (lane = d) and walks the keys with the probabilities broadcast through LDS.
-__global__ __launch_bounds__(64) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc, int H,
-                                                          int64_t Lmax, int n_keys, bf16_t* __restrict__ o) {
-    extern __shared__ float probs[];            // [n_keys rounded up to 64]
-    const int lane = threadIdx.x;
+// One new token per sequence against the KV cache (larp_ar.py:138-190 with `mask = causal_mask[:, None, input_pos]`): q [64] of the
+// new token, caches k, v [Bmax, H, Lmax, 64] bf16, keys 0..n_keys-1 visible.  HBM-bound (the cache is read once: 256 B per key
+// and head), so: one 4-wave workgroup per (b, h), the 8-key groups dealt round-robin to the waves; a wave reads a group as
+// 8 rows x 128 B with 16 B per lane (lane = 8 * key_in_group + chunk), i.e. one fully coalesced 1 KB access per instruction.
+//   phase 1: scores s = q.k / 8 (8-lane shuffle reduction per key) into LDS, running maximum
+//   phase 2: p = exp(s - max) in LDS, sum
+//   phase 3: o = sum_k bf16(p_k / sum) v_k : each lane accumulates ITS key slot's contribution to its 8 dims; slots and waves are
+//            reduced at the end (fixed order => bit-reproducible)
+// STEP variant (the generation loop): the position comes from DEVICE memory (`pos_dev`: number of earlier keys), the new token's
+// k and v are taken from the packed projection row qkv[b] = [q | k | v], stored into the caches at `pos` and used from registers --
+// no host synchronisation and no separate cache-update launches, so a whole decode step can sit in one hipGraph.
+template <bool STEP>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restrict__ q_or_qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int H, int64_t Lmax,
+                                                           int n_keys_arg, const int* __restrict__ pos_dev, bf16_t* __restrict__ o) {
+    extern __shared__ float probs[];            // [keys rounded up to 32] scores -> probabilities
+    __shared__ float red[4][64];
+    __shared__ float red_m[4], red_s[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = lane >> 3, chunk = lane & 7;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const bf16_t* qp = q + ((int64_t)b * H + h) * 64;
-    const bf16_t* kp = kc + ((int64_t)b * H + h) * Lmax * 64;
-    const bf16_t* vp = vc + ((int64_t)b * H + h) * Lmax * 64;
-    float qv[64];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bf16x8 t = *(const bf16x8*)(qp + 8 * c);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qv[8 * c + i] = bf2f(t[i]);
+    const int D = H * 64;
+    int n_keys = n_keys_arg, pos = -1;
+    const bf16_t *qp, *knew = nullptr, *vnew = nullptr;
+    if constexpr (STEP) {
+        pos = *pos_dev;
+        pos = pos < 0 ? 0 : pos;
+        const bf16_t* row = q_or_qkv + (int64_t)b * 3 * D + h * 64;
+        qp = row, knew = row + D, vnew = row + 2 * D;
+        if (pos >= Lmax) pos = (int)Lmax - 1;       // caller error (checked on the host where the position is known); stay in bounds
+        n_keys = pos + 1;
+    } else {
+        qp = q_or_qkv + ((int64_t)b * H + h) * 64;
     }
+    bf16_t* kp = kc + ((int64_t)b * H + h) * Lmax * 64;
+    bf16_t* vp = vc + ((int64_t)b * H + h) * Lmax * 64;
+    if (STEP && wave == 0 && lane < 16) {           // the new token enters the cache
+        const int c = lane & 7;
+        if (lane < 8) *(bf16x8*)(kp + (int64_t)pos * 64 + 8 * c) = *(const bf16x8*)(knew + 8 * c);
+        else *(bf16x8*)(vp + (int64_t)pos * 64 + 8 * c) = *(const bf16x8*)(vnew + 8 * c);
+    }
+    const V8 qv = ld8(qp + 8 * chunk);
+    const int groups = (n_keys + 7) / 8;
+    // phase 1
     float mx = -__builtin_inff();
-    for (int k0 = 0; k0 < n_keys; k0 += 64) {
-        const int key = k0 + lane;
-        float s = -__builtin_inff();
-        if (key < n_keys) {
-            s = 0.f;
+    for (int g0 = wave; g0 < groups; g0 += 16) {         // 4 groups of 8 keys per wave in flight
+        V8 kv[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const bf16x8 t = *(const bf16x8*)(kp + (int64_t)key * 64 + 8 * c);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s = fmaf(qv[8 * c + i], bf2f(t[i]), s);
-            }
-            s *= 0.125f;
+        for (int u = 0; u < 4; ++u) {
+            const int key = (g0 + 4 * u) * 8 + slot;
+            const bf16_t* src = (STEP && key == pos) ? knew : kp + (int64_t)(key < n_keys ? key : 0) * 64;
+            kv[u] = ld8(src + 8 * chunk);
         }
-        probs[key] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = (g0 + 4 * u) * 8 + slot;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(qv.v[i], kv[u].v[i], s);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s = key < n_keys ? s * 0.125f : -__builtin_inff();
+            if (chunk == 0 && g0 + 4 * u < groups) probs[key] = s;
+            mx = fmaxf(mx, s);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) red_m[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    // phase 2
     float sum = 0.f;
-    for (int k0 = 0; k0 < n_keys; k0 += 64) {
-        const float p = __expf(probs[k0 + lane] - mx);     // exp(-inf) = 0 for the padded keys
-        probs[k0 + lane] = p;
+    for (int k = tid; k < groups * 8; k += 256) {
+        const float p = __expf(probs[k] - mx);     // exp(-inf) = 0 for the padded keys
+        probs[k] = p;
         sum += p;
     }
     sum = wave_sum(sum);
+    if (lane == 0) red_s[wave] = sum;
     __syncthreads();
-    float acc = 0.f;
-    for (int key = 0; key < n_keys; ++key) acc = fmaf(round_bf16(probs[key] / sum), bf2f(vp[(int64_t)key * 64 + lane]), acc);
-    o[((int64_t)b * H + h) * 64 + lane] = f2bf(acc);
+    sum = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+    const float inv = 1.0f / sum;
+    // phase 3
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int g0 = wave; g0 < groups; g0 += 16) {
+        V8 vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = (g0 + 4 * u) * 8 + slot;
+            const bf16_t* src = (STEP && key == pos) ? vnew : vp + (int64_t)(key < n_keys ? key : 0) * 64;
+            vv[u] = ld8(src + 8 * chunk);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = (g0 + 4 * u) * 8 + slot;
+            const float pr = key < n_keys ? round_bf16(probs[key] * inv) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(pr, vv[u].v[i], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8);
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    if (slot == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[wave][8 * chunk + i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float r = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        o[((int64_t)b * H + h) * 64 + tid] = f2bf(r);
+    }
 }
 
 int grid_for(int64_t units) {
@@ -249,10 +317,21 @@ extern "C" int vt_swiglu_bwd(const void* da, const void* h, int64_t M, int32_t I
 extern "C" int vt_decode_attention(const void* q, const void* k_cache, const void* v_cache, int32_t B, int32_t H, int64_t Lmax, int32_t n_keys, void* o,
                                    vtStream stream) {
     VT_CHECK_ARG(q && k_cache && v_cache && o && B > 0 && H > 0 && n_keys > 0 && n_keys <= Lmax, "vt_decode_attention: bad arguments (1 <= n_keys <= Lmax)");
-    VT_CHECK_ARG(n_keys <= 16384, "vt_decode_attention: n_keys %d > 16384", n_keys);
-    const size_t lds = (size_t)((n_keys + 63) / 64 * 64) * sizeof(float);
-    hipLaunchKernelGGL(decode_attn_kernel, dim3(B * H), dim3(64), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, H,
-                       Lmax, n_keys, (bf16_t*)o);
+    VT_CHECK_ARG(n_keys <= 12288, "vt_decode_attention: n_keys %d > 12288", n_keys);
+    const size_t lds = (size_t)((n_keys + 7) / 8 * 8) * sizeof(float);
+    hipLaunchKernelGGL(decode_attn_kernel<false>, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)v_cache, H, Lmax,
+                       n_keys, (const int*)nullptr, (bf16_t*)o);
     VT_CHECK_LAUNCH("vt_decode_attention");
+    return VT_OK;
+}
+
+extern "C" int vt_decode_attention_step(const void* qkv, void* k_cache, void* v_cache, int32_t B, int32_t H, int64_t Lmax, const int32_t* pos_dev, void* o,
+                                        vtStream stream) {
+    VT_CHECK_ARG(qkv && k_cache && v_cache && pos_dev && o && B > 0 && H > 0 && Lmax > 0, "vt_decode_attention_step: bad arguments");
+    VT_CHECK_ARG(Lmax <= 12288, "vt_decode_attention_step: Lmax %ld > 12288", (long)Lmax);
+    const size_t lds = (size_t)((Lmax + 7) / 8 * 8) * sizeof(float);      // the position is only known on the device: size for the whole cache
+    hipLaunchKernelGGL(decode_attn_kernel<true>, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)k_cache, (bf16_t*)v_cache, H, Lmax, 0,
+                       (const int*)pos_dev, (bf16_t*)o);
+    VT_CHECK_LAUNCH("vt_decode_attention_step");
     return VT_OK;
 }

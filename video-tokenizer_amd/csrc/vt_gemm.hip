@@ -314,6 +314,76 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ skinny NT (M <= 64)
+// The KV-cache decode loop of the AR prior multiplies a handful of token rows (M = batch, 1-64) with every weight matrix:
+// weight-streaming, latency-bound work on which a 128- or 192-row tile wastes the chip (N / 128 workgroups, each walking
+// all of K serially: 13-24 us per launch at M = 16).  Here a 4-wave workgroup owns 16 weight rows (N / 16 workgroups), the
+// waves deal the 32-wide k-steps round-robin (so together they read each weight row in adjacent 64-B pieces), every lane
+// keeps 4 steps of loads in flight, and the four partial 16 x M accumulators are summed through LDS in a fixed order.
+// A-operand = weight rows, B-operand = token rows: a lane ends up with 4 consecutive n of one token, as in the tile kernels,
+// so the shared epilogue applies unchanged.
+template <int EPI, int MT>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const vtGemmNT p) {
+    __shared__ float red[4][MT * 16 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    int wrow = n0 + fr;
+    wrow = wrow < p.N ? wrow : p.N - 1;
+    const bf16_t* wp = (const bf16_t*)p.B + (int64_t)wrow * p.ldb + 8 * fq;
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int r = t * 16 + fr;
+        r = r < p.M ? r : p.M - 1;
+        xp[t] = (const bf16_t*)p.A + (int64_t)r * p.lda + 8 * fq;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int steps = p.K / 32;
+    for (int s0 = wave; s0 < steps; s0 += 16) {
+        bf16x8 wf[4], xf[4][MT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = s0 + 4 * u;
+            const int kk = (ks < steps ? ks : s0) * 32;          // past the end: re-read a valid piece, not accumulated
+            wf[u] = *(const bf16x8*)(wp + kk);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xf[u][t] = *(const bf16x8*)(xp[t] + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + 4 * u < steps) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][t], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)(&red[wave][(t * 16 + fr) * 16 + 4 * fq]) = acc[t];
+    __syncthreads();
+    const int m = tid >> 2, g = tid & 3;
+    if (m < p.M && m < MT * 16) {
+        const f32x4 v = (*(const f32x4*)(&red[0][m * 16 + 4 * g]) + *(const f32x4*)(&red[1][m * 16 + 4 * g])) +
+                        (*(const f32x4*)(&red[2][m * 16 + 4 * g]) + *(const f32x4*)(&red[3][m * 16 + 4 * g]));
+        const int n = n0 + 4 * g;
+        if (n < p.N) nt_epilogue<EPI>(p, RowMap{p.omap.grp, p.omap.stride, p.omap.off}, m, n, v);
+    }
+}
+
+template <int EPI>
+static void launch_skinny(const vtGemmNT& p, hipStream_t s) {
+    const dim3 grid((p.N + 15) / 16), block(256);
+    const int mt = (p.M + 15) / 16;
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, 1>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, 2>), grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, 3>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, 4>), grid, block, 0, s, p); break;
+    }
+}
+
 }  // namespace
 
 int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half);
@@ -323,7 +393,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
     const int g_gemm_variant = p.tile;   // per call (vtGemmNT.tile); the library holds no tile setting of its own
-    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 6, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup; 3/4 timing ablations)", g_gemm_variant);
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 7, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4 timing ablations)", g_gemm_variant);
     VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
@@ -348,7 +418,21 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     // ahead whenever its tiles fill whole rounds of the 256 CUs (every tokenizer shape: 256 / 768 / 1024 tiles).  Shapes
     // that leave its last round mostly empty (the discriminator's M = 8 x 1025, N = 384 / 1152: 86 or 258 tiles) finish
     // sooner on 128x128 tiles, two workgroups per CU.
-    bool big = g_gemm_variant >= 2 || p.colsum_partial;
+    // M <= 64 (the AR prior's decode steps): the weight-streaming kernel, N / 16 workgroups
+    if (g_gemm_variant == 7 || (g_gemm_variant == 0 && p.M <= 64 && !p.colsum_partial && p.N >= 64)) {
+        VT_CHECK_ARG(p.M <= 64 && !p.colsum_partial, "vt_gemm_nt: tile 7 (skinny) needs M <= 64 and no colsum_partial (M=%d)", p.M);
+        hipStream_t s = (hipStream_t)stream;
+        switch (p.epi) {
+            case VT_EPI_BF16: launch_skinny<VT_EPI_BF16>(p, s); break;
+            case VT_EPI_BF16_GELU: launch_skinny<VT_EPI_BF16_GELU>(p, s); break;
+            case VT_EPI_F32: launch_skinny<VT_EPI_F32>(p, s); break;
+            case VT_EPI_BF16_DGELU: launch_skinny<VT_EPI_BF16_DGELU>(p, s); break;
+            default: vt_set_error("vt_gemm_nt: unknown epilogue %d", p.epi); return VT_ERR_INVALID;
+        }
+        VT_CHECK_LAUNCH("vt_gemm_nt(skinny)");
+        return VT_OK;
+    }
+    bool big = (g_gemm_variant >= 2 && g_gemm_variant != 7) || p.colsum_partial;
     if (g_gemm_variant == 0 && !big && p.N >= 192 && p.M >= 192) {
         // cost in units of one full round of 192x192 tiles (256 workgroups, one per CU).  A partly filled last round of
         // that kernel costs a whole round; the 128x128 kernel runs two workgroups per CU (512 per round, a round ~1.05 of

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vt_swiglu_fwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "vt_swiglu_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "vt_decode_attention": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    "vt_decode_attention_step": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp]),
 }
 
 
@@ -428,6 +429,19 @@ def decode_attention(q, k_cache, v_cache, n_keys):
     assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[1] == H and k_cache.shape[3] == 64 and k_cache.shape[0] >= B
     o = torch.empty_like(q)
     check(lib().vt_decode_attention(ptr(q), ptr(k_cache), ptr(v_cache), B, H, k_cache.shape[2], n_keys, ptr(o), stream()), "vt_decode_attention")
+    return o
+
+
+def decode_attention_step(qkv, k_cache, v_cache, pos_dev):
+    """qkv bf16 [B, 3 * H * 64] = [q | k | v] of the new token; pos_dev int32 device tensor [1] = its position.  Stores k, v into the
+    caches at that position and returns o bf16 [B, H * 64] over keys 0..pos.  No host synchronisation (graph-capturable)."""
+    require_gpu(qkv, k_cache, v_cache, pos_dev)
+    B = qkv.shape[0]
+    H = k_cache.shape[1]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * 64 and k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[0] >= B
+    assert pos_dev.dtype == torch.int32 and pos_dev.numel() == 1
+    o = torch.empty(B, H * 64, device=qkv.device, dtype=torch.bfloat16)
+    check(lib().vt_decode_attention_step(ptr(qkv), ptr(k_cache), ptr(v_cache), B, H, k_cache.shape[2], ptr(pos_dev), ptr(o), stream()), "vt_decode_attention_step")
     return o
 
 

@@ -289,16 +289,16 @@ class TransformerBlock(nn.Module):
         x2 = x.contiguous().reshape(B * T, D).float()
         y, _ = hip.rmsnorm_fwd(x2, _f32(self.attention_norm.weight), self.attention_norm.eps)
         qkv = hip.gemm_nt(y, _pack(at, "wqkv")[0], hip.EPI_BF16)                          # [B * T, 3D] = q | k | v
-        q, k, v = (t.reshape(B, T, H, 64).transpose(1, 2) for t in qkv.split(D, dim=-1))     # [B, H, T, 64]
-        kc, vc = at.kv_cache.update(input_pos, k, v)
-        if T == 1:
-            o = hip.decode_attention(q.reshape(B, H, 64).contiguous(), kc, vc, int(input_pos[-1]) + 1).reshape(B, D)
+        if T == 1:      # one new token: cache update + attention in one launch, position read on the device (graph-capturable)
+            pos = input_pos if input_pos.dtype == torch.int32 else input_pos.to(torch.int32)
+            o = hip.decode_attention_step(qkv, at.kv_cache.k_cache, at.kv_cache.v_cache, pos[-1:])
         else:
             if int(input_pos[0]) != 0 or T != int(input_pos[-1]) + 1:
                 raise NotImplementedError("KV-cache prefill is built for a prefix that starts at position 0")
+            k, v = (t.reshape(B, T, H, 64).transpose(1, 2) for t in qkv.split(D, dim=-1)[1:])  # [B, H, T, 64]
+            at.kv_cache.update(input_pos, k, v)
             o, _ = hip.attention_causal_fwd(qkv, B, T, H)
-        a = hip.gemm_nt(o, _pack(at, "wo")[0], hip.EPI_F32, round_bf16=True)
-        h = x2 + a
+        h = hip.gemm_nt(o, _pack(at, "wo")[0], hip.EPI_F32, round_bf16=True, residual=x2)
         y2, _ = hip.rmsnorm_fwd(h, _f32(self.ffn_norm.weight), self.ffn_norm.eps)
         g = hip.swiglu_fwd(hip.gemm_nt(y2, _pack(ff, "w3", "w1")[0], hip.EPI_BF16))
         out = hip.gemm_nt(g, _pack(ff, "w2")[0], hip.EPI_F32, round_bf16=True, residual=h)
@@ -404,8 +404,13 @@ class LARP_AR(nn.Module):
         h = h.float()
         for layer in self.layers:
             h = layer(h, input_pos, cached)
-        h = self.norm(h)
-        logits = LinearFn.apply(h, self.output.weight, None)
+        if cached:
+            y, _ = hip.rmsnorm_fwd(h.reshape(-1, h.shape[-1]), _f32(self.norm.weight), self.norm.eps)
+            V = self.output.weight.shape[0]
+            logits = hip.gemm_nt(y, _pack(self, "output")[0], hip.EPI_F32, round_bf16=True, out=torch.empty(y.shape[0], (V + 3) // 4 * 4, device=y.device))
+            logits = logits[:, :V].reshape(h.shape[0], h.shape[1], V)
+        else:
+            logits = LinearFn.apply(self.norm(h), self.output.weight, None)
         if self.training or (self.frame_prediction and not self.is_sampling):
             logits = logits[:, self.cls_token_num - 1:].contiguous()
         loss = None
@@ -441,7 +446,7 @@ def top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("Inf")
     """ar/generate.py:13-52"""
     if top_k > 0:
         top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
-        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = filter_value
+        logits = logits.masked_fill(logits < torch.topk(logits, top_k)[0][..., -1, None], filter_value)
     if top_p < 1.0:
         sorted_logits, sorted_indices = torch.sort(logits, descending=True)
         remove = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1) > top_p
@@ -449,7 +454,7 @@ def top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("Inf")
             remove[..., :min_tokens_to_keep] = 0
         remove[..., 1:] = remove[..., :-1].clone()
         remove[..., 0] = 0
-        logits[remove.scatter(1, sorted_indices, remove)] = filter_value
+        logits = logits.masked_fill(remove.scatter(1, sorted_indices, remove), filter_value)
     return logits
 
 
@@ -470,9 +475,18 @@ def _guided(logits, cfg_scale, use_cfg=True):
     return logits
 
 
+GRAPH_WARM = 2          # decode iterations run eagerly before the step is captured
+GRAPH_MIN_STEPS = 8     # shorter generations are not worth a capture
+
+
 @torch.no_grad()
-def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, **sampling_kwargs):
-    """ar/generate.py:126-174: prefill the conditioning token(s), then decode max_new_tokens - 1 tokens one at a time through the KV cache"""
+def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, use_graph=None, **sampling_kwargs):
+    """ar/generate.py:126-174: prefill the conditioning token(s), then decode max_new_tokens - 1 tokens one at a time through the KV cache.
+
+    A decode iteration (embedding, n_layer x [RMSNorm, wqkv, cache update + attention, wo, RMSNorm, w3|w1, SwiGLU, w2], head, guidance,
+    sampling, position += 1, token -> seq) has no host-side dependency -- the position lives on the device (vt_decode_attention_step) --
+    so after GRAPH_WARM eager iterations it is captured ONCE as a hipGraph (torch.cuda.CUDAGraph) and replayed: the loop is launch-bound
+    (~100-400 small kernels per token), the replay costs one enqueue.  use_graph=False (or VT_AR_GRAPH=0) keeps the eager loop."""
     if emb_masks is not None:
         raise NotImplementedError("emb_masks (masked frame-prediction prefixes) are not built")
     if model.frame_prediction:
@@ -490,21 +504,37 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
     seq = torch.empty((B, T_new), dtype=torch.int, device=dev)
     input_pos = torch.arange(0, T, device=dev)
     logits, _ = model(None, cond_combined, input_pos)
-    cur = sample(_guided(logits, cfg_scale), **sampling_kwargs)[0]
+    cur = sample(_guided(logits, cfg_scale), **sampling_kwargs)[0].view(-1, 1).clone()
     seq[:, T:T + 1] = cur
     input_pos = torch.tensor([T], device=dev, dtype=torch.int)
-    toks = []
-    for i in range(max_new_tokens - 1):
-        use_cfg = not (cfg_interval > -1 and i > cfg_interval)
+
+    def one_step(use_cfg):          # everything on the device; `cur`, `input_pos`, `seq` are updated in place
         x = torch.cat([cur, cur]) if cfg_scale > 1.0 else cur
-        logits, _ = model(x, cond_idx=None, input_pos=input_pos)
-        cur, _ = sample(_guided(logits, cfg_scale, use_cfg), **sampling_kwargs)
-        input_pos += 1
-        toks.append(cur.clone())
-        cur = cur.view(-1, 1)
-    if toks:
-        seq[:, T + 1:] = torch.cat(toks, dim=1)
-    return seq[:, T:]
+        lg, _ = model(x, cond_idx=None, input_pos=input_pos)
+        nxt, _ = sample(_guided(lg, cfg_scale, use_cfg), **sampling_kwargs)
+        input_pos.add_(1)
+        seq.index_copy_(1, input_pos.long(), nxt.to(torch.int32))     # iteration i fills column T + 1 + i = the incremented position
+        cur.copy_(nxt.view(-1, 1))
+
+    n_rest = max_new_tokens - 1
+    if use_graph is None:
+        use_graph = os.environ.get("VT_AR_GRAPH", "1") != "0"
+    use_graph = use_graph and n_rest >= GRAPH_MIN_STEPS
+    graphs = {}
+    for i in range(n_rest):
+        use_cfg = not (cfg_interval > -1 and i > cfg_interval)
+        if not use_graph or i < GRAPH_WARM:
+            one_step(use_cfg)
+            continue
+        g = graphs.get(use_cfg)
+        if g is None:
+            g = graphs[use_cfg] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step(use_cfg)
+        g.replay()
+    out = seq[:, T:].clone()
+    del graphs
+    return out
 
 
 def _make(n_layer, n_head, dim):
