@@ -100,8 +100,8 @@ def time_dominant_kernel(B, c, reps=20):
 def measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from PMC counters (cannot be collected inside this process):
     the rocprofv3 passes of tools/pmc_traffic.sh, committed under profiles/."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemm_nt192.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (2, 1)) if os.path.exists(q)), None)
+    if path is None:
         return None
     with open(path) as f:
         return int(json.load(f)["traffic_bytes_per_launch_mean"])
@@ -139,6 +139,55 @@ def fsq_autoencoder_step(vt, name, steps, warmup, clips=4):
     dt = (time.perf_counter() - t0) / steps
     return {"model": name, "parameters_M": round(sum(q.numel() for q in m.parameters()) / 1e6, 1), "clips_per_step": clips,
             "ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(clips / dt, 2), "tflops": round(clips * flops / dt / 1e12, 1)}
+
+
+def ar_prior_step(vt, size, steps, warmup, batch=8, seq=1024, gen_batch=16, vocab=8192, mode="both"):
+    """Secondary figure: LARP_AR `llama-abs-<size>` over the tokenizer's indices (vocab 8192, 1024 tokens per clip:
+    cfgs/larp_ar.yaml geometry) -- training step (forward, cross-entropy, backward; dropout at the reference's 0.1) and class-conditional
+    generation through the KV cache (ar/generate.py: prefill + one token per position, with and without classifier-free guidance)."""
+    m = vt.registry.make({"name": f"llama-abs-{size}", "args": dict(vocab_size=vocab, max_seq_len=seq, num_classes=101)}).cuda()
+    torch.nn.init.normal_(m.output.weight, std=0.02)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tok = torch.randint(0, vocab, (batch, seq), device="cuda", generator=g)
+    lab = torch.randint(0, 101, (batch,), device="cuda", generator=g)
+    res = {"model": f"llama-abs-{size}", "parameters_M": round(sum(p.numel() for p in m.parameters()) / 1e6, 1)}
+    if mode in ("both", "train"):
+        m.train()
+
+        def step():
+            for p in m.parameters():
+                p.grad = None
+            loss = m(tok[:, :-1], lab, targets=tok)[1]
+            loss.backward()
+            return loss
+
+        for _ in range(max(warmup, 2)):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        c = m.config
+        hidden = m.layers[0].feed_forward.w1.weight.shape[0]
+        per_tok = c.n_layer * (2 * c.dim * (4 * c.dim + 3 * hidden) + 2 * seq * c.dim) + 2 * c.dim * c.vocab_size      # forward flops per token, causal attention
+        res["train"] = {"batch": batch, "seq": seq, "ms_per_step": round(dt * 1e3, 2), "tokens_per_s": round(batch * seq / dt),
+                        "model_tflops": round(3 * per_tok * batch * seq / dt / 1e12, 1), "loss": round(loss.item(), 4)}
+    if mode in ("both", "gen"):
+        m.eval()
+        cond = torch.randint(0, 101, (gen_batch,), device="cuda", generator=g)
+        for scale in (1.0, 2.0):
+            for timed in (False, True):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = m.sample(cond, cfg_scale=scale, temperature=1.0, top_k=0, top_p=1.0)
+                m.reset_caches()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            res[f"generate_cfg{scale:g}"] = {"sequences": gen_batch, "new_tokens": int(out.shape[1]), "s": round(dt, 3), "tokens_per_s": round(gen_batch * out.shape[1] / dt),
+                                             "ms_per_position": round(dt / out.shape[1] * 1e3, 3)}
+    return res
 
 
 def gan_step(vt, model, x, steps, warmup):
@@ -212,6 +261,9 @@ def main():
                     help="also time fwd+bwd of one of the FSQ autoencoders (autoencoder_large, autoencoder_convpatchify, "
                          "autoencoder_convpatchify_greatfsq; cfgs/larp_tokenizer_large.yaml:37) at the reference geometry, 4 clips: "
                          "extra key 'fsq_autoencoder_step'; the headline metric is unchanged")
+    ap.add_argument("--ar", default=None, metavar="SIZE",
+                    help="also time the AR prior llama-abs-SIZE (S, B, L, LP, XL, XXL, XXXL; models/larp_ar.py:449-468) over 8192-code indices, "
+                         "1024 tokens per clip: training step and KV-cache generation; extra key 'ar_prior'; the headline metric is unchanged")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -349,6 +401,11 @@ def main():
                 res["fsq_autoencoder_step"] = fsq_autoencoder_step(vt, a.fsq_ae, a.steps, a.warmup)
             except Exception as e:  # noqa: BLE001
                 res["fsq_autoencoder_step"] = {"error": repr(e)}
+        if a.ar and world == 1:
+            try:
+                res["ar_prior"] = ar_prior_step(vt, a.ar, a.steps, a.warmup)
+            except Exception as e:  # noqa: BLE001
+                res["ar_prior"] = {"error": repr(e)}
         if not a.no_roofline:
             try:
                 ach, per, _ = time_dominant_kernel(B, c)
