@@ -300,6 +300,13 @@ int vt_decode_attention(const void* q, const void* k_cache, const void* v_cache,
                         vtStream stream);
 int vt_decode_attention_step(const void* qkv, void* k_cache, void* v_cache, int32_t B, int32_t H, int64_t Lmax, const int32_t* pos_dev, void* o,
                              vtStream stream);
+/* vt_decode_norm_linear: Linear(RMSNorm(x)) for the M <= 64 token rows of a decode step as ONE launch (x fp32 [M, K], norm_w fp32 [K],
+ * W bf16 [N, K] row-major, K % 128 == 0, N % 16 == 0).  mode 0: out bf16 [M, ldo >= N] (wqkv); mode 1: W = [w3 ; w1] interleaved in slabs
+ * of 8 + 8 rows, out bf16 [M, ldo >= N / 2] = silu(w1 y) * (w3 y) (FeedForward, larp_ar.py:135); mode 2: out fp32 [M, ldo >= N] holding
+ * the bf16-rounded values (the LM head).  Bit-identical to vt_rmsnorm_fwd + vt_gemm_nt(tile 7) [+ vt_swiglu_fwd].
+ * norm_w == NULL: x is the already normalised bf16 [M, K] operand (only the Linear and its epilogue are fused). */
+int vt_decode_norm_linear(const void* x, const float* norm_w, float eps, const void* W_bf16, int32_t M, int32_t N, int32_t K, int32_t mode, void* out,
+                          int64_t ldo, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * A stack of those layers as ONE enqueue per direction: `ResidualAttentionBlock.forward` (transformer.py:66-91) and the

@@ -157,6 +157,26 @@ def test_decode_attention_step_updates_cache_and_matches_torch(pos):
     assert torch.equal(o2.reshape(B, D), o)
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 384, 1152), (16, 768, 2304), (33, 1024, 4096), (64, 2560, 512)])
+def test_decode_norm_linear_is_bit_identical_to_the_separate_kernels(M, K, N):
+    """RMSNorm folded into the weight-streaming GEMM (and SwiGLU into its epilogue): same bits as rmsnorm -> skinny GEMM -> swiglu"""
+    from video_tokenizer_amd import hip
+    x = torch.from_numpy(gen.normal((M, K), 91, 1.5)).cuda()
+    nw = 1.0 + torch.from_numpy(gen.normal((K,), 92, 0.2)).cuda()
+    W = torch.from_numpy(gen.normal((N, K), 93, 0.05)).cuda().to(torch.bfloat16)
+    y, _ = hip.rmsnorm_fwd(x, nw, 1e-5)
+    ref_bf = hip.gemm_nt(y, W, hip.EPI_BF16, tile=7)
+    assert torch.equal(hip.decode_norm_linear(x, nw, 1e-5, W, mode=0), ref_bf)
+    assert torch.equal(hip.decode_norm_linear(x, nw, 1e-5, W, mode=2), hip.gemm_nt(y, W, hip.EPI_F32, round_bf16=True, tile=7))
+    I = N // 2                                                   # rows 0..I-1 play w3, I..2I-1 play w1
+    Wi = torch.cat([W[:I].reshape(I // 8, 8, K), W[I:].reshape(I // 8, 8, K)], dim=1).reshape(N, K).contiguous()
+    assert torch.equal(hip.decode_norm_linear(x, nw, 1e-5, Wi, mode=1), hip.swiglu_fwd(ref_bf))
+    assert torch.equal(hip.decode_norm_linear(y, None, 0.0, Wi, mode=1), hip.swiglu_fwd(ref_bf))        # pre-normalised bf16 operand
+    assert torch.equal(hip.decode_norm_linear(y, None, 0.0, W, mode=0), ref_bf)
+    ref = (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * nw).to(torch.bfloat16).float() @ W.float().t()
+    assert rel(ref_bf, ref) < 4e-3
+
+
 # ------------------------------------------------------------------------------------------------ the module
 def build(name, **over):
     import video_tokenizer_amd as vt
@@ -242,6 +262,16 @@ def test_graph_replayed_generation_equals_eager_loop():
                                  sample_logits=False))
         m.reset_caches()
     assert torch.equal(outs[0], outs[1])
+    for level in ("0", "norm"):                                                 # and to the other fusion levels of the decode kernels (same bits by construction)
+        os.environ["VT_AR_FUSED_DECODE"] = level
+        try:
+            with m.sampling():
+                other = generate(m, cond.cuda(), cfg["max_seq_len"], cfg_scale=3.0, cfg_interval=20, use_graph=False, temperature=1.0, top_k=0, top_p=1.0,
+                                 sample_logits=False)
+            m.reset_caches()
+        finally:
+            del os.environ["VT_AR_FUSED_DECODE"]
+        assert torch.equal(outs[0], other), level
     torch.manual_seed(3)
     with m.sampling():                                                          # sampled path (top-k / top-p / multinomial inside the graph): valid tokens
         s = generate(m, cond.cuda(), cfg["max_seq_len"], cfg_scale=1.0, use_graph=True, temperature=0.8, top_k=40, top_p=0.9, sample_logits=True)

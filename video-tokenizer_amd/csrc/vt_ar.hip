@@ -261,6 +261,141 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- decode step: RMSNorm + Linear [+ SwiGLU]
+// One node of the generation graph instead of two or three: y = Linear(RMSNorm(x)) for the M <= 64 token rows of a decode step.
+// A workgroup owns 16 weight rows (as gemm_nt_skinny_kernel); it first computes the M row scales itself (the rows are a few KB,
+// L2-resident; same summation order as rmsnorm_fwd_kernel, so the result is bit-identical to the two-kernel path), then forms the
+// bf16 operand fragments bf16(x * rstd * w) on the fly.  MODE 0: bf16 output (wqkv).  MODE 1: the weight is [w3 ; w1] interleaved in
+// slabs of 8 + 8 rows, the epilogue applies SwiGLU with autocast's rounding points and writes a [M, N / 2].  MODE 2: fp32 output of
+// the bf16-rounded value (the LM head's logits).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int MT, int MODE, bool NORM>
+__global__ __launch_bounds__(256) void decode_norm_linear_kernel(const void* __restrict__ xin, const float* __restrict__ nw, float eps, const bf16_t* __restrict__ W,
+                                                                  int M, int N, int K, void* __restrict__ out, int64_t ldo) {
+    __shared__ float red[4][MT * 16 * 16];
+    __shared__ float rs[MT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (NORM) {       // the row scales: this wave's MT * 4 rows side by side (independent loads), each in rmsnorm_fwd_kernel's order
+        const float* x = (const float*)xin;
+        constexpr int RW = MT * 4;
+        float ss[RW];
+        const f32x2* xr[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int m = wave + 4 * r;
+            xr[r] = (const f32x2*)(x + (int64_t)(m < M ? m : M - 1) * K);
+            ss[r] = 0.f;
+        }
+        for (int j = 0; j < K / 128; ++j) {
+            f32x2 v[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) v[r] = xr[r][j * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                ss[r] = fmaf(v[r][0], v[r][0], ss[r]);
+                ss[r] = fmaf(v[r][1], v[r][1], ss[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float t = wave_sum(ss[r]);
+            if (lane == 0) rs[wave + 4 * r] = __builtin_amdgcn_rsqf(t * (1.0f / K) + eps);
+        }
+        __syncthreads();
+    }
+    int wrow = n0 + fr;
+    wrow = wrow < N ? wrow : N - 1;
+    const bf16_t* wp = W + (int64_t)wrow * K + 8 * fq;
+    int64_t xoff[MT];
+    float rstd[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int r = t * 16 + fr;
+        rstd[t] = NORM ? rs[r] : 1.f;
+        r = r < M ? r : M - 1;
+        xoff[t] = (int64_t)r * K + 8 * fq;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int steps = K / 32;
+    constexpr int U = NORM ? (MT <= 2 ? 4 : 2) : 4;      // k-steps per wave in flight
+    for (int s0 = wave; s0 < steps; s0 += 4 * U) {
+        bf16x8 wf[U], xf[U][MT];
+        if constexpr (NORM) {
+            const float* x = (const float*)xin;
+            f32x4v xa[U][MT], xb[U][MT], na[U], nb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = s0 + 4 * u;
+                const int kk = (ks < steps ? ks : s0) * 32;
+                wf[u] = *(const bf16x8*)(wp + kk);
+                na[u] = *(const f32x4v*)(nw + kk + 8 * fq);
+                nb[u] = *(const f32x4v*)(nw + kk + 8 * fq + 4);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    xa[u][t] = *(const f32x4v*)(x + xoff[t] + kk);
+                    xb[u][t] = *(const f32x4v*)(x + xoff[t] + kk + 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xf[u][t][i] = f2bf(xa[u][t][i] * rstd[t] * na[u][i]);
+                        xf[u][t][4 + i] = f2bf(xb[u][t][i] * rstd[t] * nb[u][i]);
+                    }
+        } else {
+            const bf16_t* x = (const bf16_t*)xin;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = s0 + 4 * u;
+                const int kk = (ks < steps ? ks : s0) * 32;
+                wf[u] = *(const bf16x8*)(wp + kk);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) xf[u][t] = *(const bf16x8*)(x + xoff[t] + kk);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s0 + 4 * u < steps) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][t], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)(&red[wave][(t * 16 + fr) * 16 + 4 * fq]) = acc[t];
+    __syncthreads();
+    const int m = tid >> 2, g = tid & 3;
+    if (m >= M || m >= MT * 16) return;
+    auto total = [&](int c4) {
+        return (*(const f32x4*)(&red[0][m * 16 + 4 * c4]) + *(const f32x4*)(&red[1][m * 16 + 4 * c4])) +
+               (*(const f32x4*)(&red[2][m * 16 + 4 * c4]) + *(const f32x4*)(&red[3][m * 16 + 4 * c4]));
+    };
+    if constexpr (MODE == 1) {
+        if (g < 2) {            // hidden units 4g..4g+3 of this slab: value rows 4g.., gate rows 8 + 4g..
+            const f32x4 xv = total(g), gv = total(2 + g);
+            bf16x4 r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = f2bf(round_bf16(silu_f(round_bf16(gv[i]))) * round_bf16(xv[i]));
+            *(bf16x4*)((bf16_t*)out + (int64_t)m * ldo + blockIdx.x * 8 + 4 * g) = r;
+        }
+    } else {
+        const f32x4 v = total(g);
+        const int n = n0 + 4 * g;
+        if (n < N) {
+            if constexpr (MODE == 0) *(bf16x4*)((bf16_t*)out + (int64_t)m * ldo + n) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            else *(f32x4*)((float*)out + (int64_t)m * ldo + n) = (f32x4){round_bf16(v[0]), round_bf16(v[1]), round_bf16(v[2]), round_bf16(v[3])};
+        }
+    }
+}
+
 int grid_for(int64_t units) {
     const int64_t b = (units + 255) / 256;
     return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);
@@ -333,5 +468,27 @@ extern "C" int vt_decode_attention_step(const void* qkv, void* k_cache, void* v_
     hipLaunchKernelGGL(decode_attn_kernel<true>, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)k_cache, (bf16_t*)v_cache, H, Lmax, 0,
                        (const int*)pos_dev, (bf16_t*)o);
     VT_CHECK_LAUNCH("vt_decode_attention_step");
+    return VT_OK;
+}
+
+extern "C" int vt_decode_norm_linear(const void* x, const float* norm_w, float eps, const void* W_bf16, int32_t M, int32_t N, int32_t K, int32_t mode, void* out,
+                                     int64_t ldo, vtStream stream) {
+    VT_CHECK_ARG(x && W_bf16 && out, "vt_decode_norm_linear: null pointer");
+    VT_CHECK_ARG(M > 0 && M <= 64 && N > 0 && N % 16 == 0 && K > 0 && K % 128 == 0, "vt_decode_norm_linear: M=%d (1..64) N=%d (%%16) K=%d (%%128)", M, N, K);
+    VT_CHECK_ARG(mode >= 0 && mode <= 2 && ldo % 4 == 0 && ldo >= (mode == 1 ? N / 2 : N), "vt_decode_norm_linear: mode %d / ldo %ld", mode, (long)ldo);
+    VT_CHECK_ARG((((uintptr_t)x | (uintptr_t)norm_w | (uintptr_t)W_bf16 | (uintptr_t)out) & 15) == 0, "vt_decode_norm_linear: pointers must be 16-byte aligned");
+    const dim3 grid(N / 16), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int mt = (M + 15) / 16;
+#define VT_DNL(MT_, MODE_, NORM_) hipLaunchKernelGGL((decode_norm_linear_kernel<MT_, MODE_, NORM_>), grid, block, 0, s, x, norm_w, eps, (const bf16_t*)W_bf16, M, N, K, out, ldo)
+#define VT_DNL_M(MODE_, NORM_) switch (mt) { case 1: VT_DNL(1, MODE_, NORM_); break; case 2: VT_DNL(2, MODE_, NORM_); break; case 3: VT_DNL(3, MODE_, NORM_); break; default: VT_DNL(4, MODE_, NORM_); break; }
+    if (norm_w) {
+        if (mode == 0) { VT_DNL_M(0, true) } else if (mode == 1) { VT_DNL_M(1, true) } else { VT_DNL_M(2, true) }
+    } else {
+        if (mode == 0) { VT_DNL_M(0, false) } else if (mode == 1) { VT_DNL_M(1, false) } else { VT_DNL_M(2, false) }
+    }
+#undef VT_DNL_M
+#undef VT_DNL
+    VT_CHECK_LAUNCH("vt_decode_norm_linear");
     return VT_OK;
 }

@@ -93,6 +93,7 @@ SIGNATURES = {
     "vt_swiglu_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "vt_decode_attention": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "vt_decode_attention_step": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "vt_decode_norm_linear": (c_i32, [c_vp, c_vp, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
 }
 
 
@@ -443,6 +444,23 @@ def decode_attention_step(qkv, k_cache, v_cache, pos_dev):
     o = torch.empty(B, H * 64, device=qkv.device, dtype=torch.bfloat16)
     check(lib().vt_decode_attention_step(ptr(qkv), ptr(k_cache), ptr(v_cache), B, H, k_cache.shape[2], ptr(pos_dev), ptr(o), stream()), "vt_decode_attention_step")
     return o
+
+
+def decode_norm_linear(x, norm_w, eps, W, mode=0):
+    """Linear(RMSNorm(x)) for M <= 64 rows in one launch.  x fp32 [M, K]; W bf16 [N, K]; mode 0 -> bf16 [M, N]; mode 1 (W = [w3 ; w1] in
+    8 + 8-row slabs) -> SwiGLU output bf16 [M, N / 2]; mode 2 -> fp32 [M, N] of the bf16-rounded values."""
+    require_gpu(x, norm_w, W)
+    M, K = x.shape
+    N = W.shape[0]
+    if norm_w is None:
+        assert x.dtype == torch.bfloat16           # already normalised operand: only the Linear and its epilogue are fused
+    else:
+        assert x.dtype == torch.float32 and norm_w.dtype == torch.float32
+    assert W.dtype == torch.bfloat16 and x.is_contiguous() and W.is_contiguous() and W.shape[1] == K
+    cols = N // 2 if mode == 1 else N
+    out = torch.empty(M, cols, device=x.device, dtype=torch.float32 if mode == 2 else torch.bfloat16)
+    check(lib().vt_decode_norm_linear(ptr(x), ptr(norm_w), eps, ptr(W), M, N, K, mode, ptr(out), cols, stream()), "vt_decode_norm_linear")
+    return out
 
 
 def vq_forward(z_in, codebook, mode, l2_normalized=True, inv_tau=1.0, beta=0.25, codebook_w=1.0, seed=0, ldp=0):

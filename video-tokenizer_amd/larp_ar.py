@@ -286,9 +286,14 @@ class TransformerBlock(nn.Module):
         at, ff = self.attention, self.feed_forward
         B, T, D = x.shape
         H = at.n_head
-        x2 = x.contiguous().reshape(B * T, D).float()
-        y, _ = hip.rmsnorm_fwd(x2, _f32(self.attention_norm.weight), self.attention_norm.eps)
-        qkv = hip.gemm_nt(y, _pack(at, "wqkv")[0], hip.EPI_BF16)                          # [B * T, 3D] = q | k | v
+        M = B * T
+        x2 = x.contiguous().reshape(M, D).float()
+        fuse = _decode_fusion() if M <= 64 else "0"         # decode-sized row counts: SwiGLU (and optionally RMSNorm) inside the weight-streaming GEMM
+        if fuse == "norm":
+            qkv = hip.decode_norm_linear(x2, _f32(self.attention_norm.weight), self.attention_norm.eps, _pack(at, "wqkv")[0])
+        else:
+            y, _ = hip.rmsnorm_fwd(x2, _f32(self.attention_norm.weight), self.attention_norm.eps)
+            qkv = hip.gemm_nt(y, _pack(at, "wqkv")[0], hip.EPI_BF16)                      # [B * T, 3D] = q | k | v
         if T == 1:      # one new token: cache update + attention in one launch, position read on the device (graph-capturable)
             pos = input_pos if input_pos.dtype == torch.int32 else input_pos.to(torch.int32)
             o = hip.decode_attention_step(qkv, at.kv_cache.k_cache, at.kv_cache.v_cache, pos[-1:])
@@ -299,10 +304,36 @@ class TransformerBlock(nn.Module):
             at.kv_cache.update(input_pos, k, v)
             o, _ = hip.attention_causal_fwd(qkv, B, T, H)
         h = hip.gemm_nt(o, _pack(at, "wo")[0], hip.EPI_F32, round_bf16=True, residual=x2)
-        y2, _ = hip.rmsnorm_fwd(h, _f32(self.ffn_norm.weight), self.ffn_norm.eps)
-        g = hip.swiglu_fwd(hip.gemm_nt(y2, _pack(ff, "w3", "w1")[0], hip.EPI_BF16))
+        if fuse == "norm":
+            g = hip.decode_norm_linear(h, _f32(self.ffn_norm.weight), self.ffn_norm.eps, _pack_swiglu(ff), mode=1)
+        elif fuse == "swiglu":
+            y2, _ = hip.rmsnorm_fwd(h, _f32(self.ffn_norm.weight), self.ffn_norm.eps)
+            g = hip.decode_norm_linear(y2, None, 0.0, _pack_swiglu(ff), mode=1)
+        else:
+            y2, _ = hip.rmsnorm_fwd(h, _f32(self.ffn_norm.weight), self.ffn_norm.eps)
+            g = hip.swiglu_fwd(hip.gemm_nt(y2, _pack(ff, "w3", "w1")[0], hip.EPI_BF16))
         out = hip.gemm_nt(g, _pack(ff, "w2")[0], hip.EPI_F32, round_bf16=True, residual=h)
         return out.reshape(B, T, D)
+
+
+def _decode_fusion():
+    """VT_AR_FUSED_DECODE: 'swiglu' (default) = SwiGLU in the epilogue of the w3|w1 GEMM; 'norm' = also RMSNorm in the operand load of
+    the wqkv / w3|w1 / head GEMMs (fewer graph nodes, but every workgroup re-reads the fp32 rows: measured slower); '0' = neither.
+    All three give the same bits."""
+    return os.environ.get("VT_AR_FUSED_DECODE", "swiglu")
+
+
+def _pack_swiglu(ff):
+    """bf16 [2I, D]: w3 and w1 interleaved in slabs of 8 + 8 rows, the operand layout of vt_decode_norm_linear(mode 1)"""
+    key = tuple((w.data_ptr(), w._version) for w in (ff.w3.weight, ff.w1.weight))
+    hit = ff.__dict__.get("_vt_pack_swiglu")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            I, K = ff.w1.weight.shape
+            w = torch.cat([ff.w3.weight.detach().reshape(I // 8, 8, K), ff.w1.weight.detach().reshape(I // 8, 8, K)], dim=1).reshape(2 * I, K)
+            hit = (key, w.to(torch.bfloat16).contiguous())
+        ff.__dict__["_vt_pack_swiglu"] = hit
+    return hit[1]
 
 
 class LARP_AR(nn.Module):
@@ -405,9 +436,13 @@ class LARP_AR(nn.Module):
         for layer in self.layers:
             h = layer(h, input_pos, cached)
         if cached:
-            y, _ = hip.rmsnorm_fwd(h.reshape(-1, h.shape[-1]), _f32(self.norm.weight), self.norm.eps)
             V = self.output.weight.shape[0]
-            logits = hip.gemm_nt(y, _pack(self, "output")[0], hip.EPI_F32, round_bf16=True, out=torch.empty(y.shape[0], (V + 3) // 4 * 4, device=y.device))
+            h2 = h.reshape(-1, h.shape[-1])
+            if h2.shape[0] <= 64 and V % 16 == 0 and _decode_fusion() == "norm":
+                logits = hip.decode_norm_linear(h2, _f32(self.norm.weight), self.norm.eps, _pack(self, "output")[0], mode=2)
+            else:
+                y, _ = hip.rmsnorm_fwd(h2, _f32(self.norm.weight), self.norm.eps)
+                logits = hip.gemm_nt(y, _pack(self, "output")[0], hip.EPI_F32, round_bf16=True, out=torch.empty(y.shape[0], (V + 3) // 4 * 4, device=y.device))
             logits = logits[:, :V].reshape(h.shape[0], h.shape[1], V)
         else:
             logits = LinearFn.apply(self.norm(h), self.output.weight, None)
