@@ -190,6 +190,37 @@ def ar_prior_step(vt, size, steps, warmup, batch=8, seq=1024, gen_batch=16, voca
     return res
 
 
+def sq_step(vt, c, spec, x, steps, warmup):
+    """Secondary figure: the same step with the bottleneck the shipped cfgs/larp_tokenizer.yaml:73 names, bottleneck_type 'sq' -- cosine search over
+    the frozen 196 560 x 24 codebook (models/larp_tokenizer.py:225-229, 423-428); loss = L1 + 0.1 * loss_codebook."""
+    import copy
+    sp = copy.deepcopy(spec)
+    sp["args"]["bottleneck_type"] = "sq"
+    m = vt.make(sp)
+    with torch.no_grad():
+        torch.nn.init.xavier_uniform_(m.final_layer.linear.weight)
+    m = m.to(x.device).train()
+
+    def step():
+        out = m(x)
+        loss = (out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_codebook"]
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        return loss
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"bottleneck_type": "sq", "codebook": "196560 x 24 (frozen, generated Leech shell)", "ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(x.shape[0] / dt, 2),
+            "loss": round(loss.item(), 5), "distinct_codes_in_batch": int(torch.unique(m.last_indices).numel())}
+
+
 def gan_step(vt, model, x, steps, warmup):
     """Secondary figure: the trainer's step with its GAN branch (larp_tokenizer_trainer.py:263-345) --
     tokenizer forward, discriminator update on the detached reconstruction every d_update_freq-th step, generator loss
@@ -261,6 +292,9 @@ def main():
                     help="also time fwd+bwd of one of the FSQ autoencoders (autoencoder_large, autoencoder_convpatchify, "
                          "autoencoder_convpatchify_greatfsq; cfgs/larp_tokenizer_large.yaml:37) at the reference geometry, 4 clips: "
                          "extra key 'fsq_autoencoder_step'; the headline metric is unchanged")
+    ap.add_argument("--sq", action="store_true",
+                    help="also time the step with bottleneck_type 'sq' (the value the shipped cfgs/larp_tokenizer.yaml:73 carries): cosine search over the frozen "
+                         "196 560 x 24 codebook; extra key 'sq_step'; the headline metric (bottleneck_type vq, BASELINE.json) is unchanged")
     ap.add_argument("--ar", default=None, metavar="SIZE",
                     help="also time the AR prior llama-abs-SIZE (S, B, L, LP, XL, XXL, XXXL; models/larp_ar.py:449-468) over 8192-code indices, "
                          "1024 tokens per clip: training step and KV-cache generation; extra key 'ar_prior'; the headline metric is unchanged")
@@ -401,6 +435,11 @@ def main():
                 res["fsq_autoencoder_step"] = fsq_autoencoder_step(vt, a.fsq_ae, a.steps, a.warmup)
             except Exception as e:  # noqa: BLE001
                 res["fsq_autoencoder_step"] = {"error": repr(e)}
+        if a.sq and world == 1:
+            try:
+                res["sq_step"] = sq_step(vt, c, spec, x, a.steps, a.warmup)
+            except Exception as e:  # noqa: BLE001
+                res["sq_step"] = {"error": repr(e)}
         if a.ar and world == 1:
             try:
                 res["ar_prior"] = ar_prior_step(vt, a.ar, a.steps, a.warmup)

@@ -274,6 +274,15 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
         sq = sq_forward(zp, p["bottleneck.embedding.weight"], force_idx=vq_kw.get("force_idx"))
         encoded = linear(sq["output"], p["sq_out_linear.weight"], p["sq_out_linear.bias"], emu)
         out = {"encoded": encoded, "loss_codebook": sq["loss_codebook"], "_indices": sq["indices"], "_projected_z": zp}
+    elif cfg.get("bottleneck_type", "vq") == "fsq":                     # :412-418: LayerNorm -> Linear(768, 6) -> FSQ([8,8,8,5,5,5]) -> Linear(6, 768)
+        from .titok_oracle import fsq as _fsq                            # models/model_new/quantizer/fsq.py:54-131, pinned by tests/golden/fsq_*.npz
+        zn = F.layer_norm(z, (z.shape[-1],), p["fsq_norm.weight"], p["fsq_norm.bias"], 1e-5)
+        zp = linear(zn, p["fsq_in_linear.weight"], p["fsq_in_linear.bias"], emu)
+        codes, idx, bounded = _fsq(zp, (8, 8, 8, 5, 5, 5))
+        if vq_kw.get("force_codes") is not None:                         # follow the device's codes downstream (rounding-boundary flips)
+            codes = codes + (vq_kw["force_codes"] - codes).detach()
+        encoded = linear(codes, p["fsq_out_linear.weight"], p["fsq_out_linear.bias"], emu)
+        out = {"encoded": encoded, "_codes": codes, "_indices": idx, "_bounded": bounded, "_projected_z": zp}   # the reference returns {'encoded'} only
     else:
         bo = bottleneck_forward(z, p, "bottleneck.", mode, emu, **vq_kw)     # :420
         encoded = bo.pop("output")
@@ -342,6 +351,13 @@ def init_state_dict(cfg, seed=1234, zero_head=False, query_std=0.02):
         sd["sq_in_linear.bias"] = T(gen.uniform((24,), nxt(), -0.02, 0.02))
         sd["sq_out_linear.weight"] = T(gen.xavier_uniform((D, 24), nxt()))
         sd["sq_out_linear.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
+    elif cfg.get("bottleneck_type", "vq") == "fsq":   # larp_tokenizer.py:219-228 (then initialize_weights xavier-inits every Linear, :318-321)
+        sd["fsq_in_linear.weight"] = T(gen.xavier_uniform((6, D), nxt()))
+        sd["fsq_in_linear.bias"] = T(gen.uniform((6,), nxt(), -0.02, 0.02))
+        sd["fsq_out_linear.weight"] = T(gen.xavier_uniform((D, 6), nxt()))
+        sd["fsq_out_linear.bias"] = T(gen.uniform((D,), nxt(), -0.02, 0.02))
+        sd["fsq_norm.weight"] = T(gen.uniform((D,), nxt(), 0.9, 1.1))
+        sd["fsq_norm.bias"] = T(gen.uniform((D,), nxt(), -0.05, 0.05))
     else:
         sd["bottleneck.in_linear.weight"] = T(gen.xavier_uniform((d, D), nxt()))
         sd["bottleneck.in_linear.bias"] = T(gen.uniform((d,), nxt(), -0.02, 0.02))

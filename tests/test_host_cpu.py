@@ -74,7 +74,7 @@ def test_from_checkpoint_roundtrip_and_extra_keys(tmp_path):
 def test_unsupported_options_fail_loudly():
     cfg = O.make_cfg("tiny")
     s = spec_from_cfg(cfg)
-    s["args"]["bottleneck_type"] = "fsq"
+    s["args"]["bottleneck_type"] = "auto"
     with pytest.raises(NotImplementedError):
         vt.make(s)
     s = spec_from_cfg(cfg)
@@ -355,7 +355,30 @@ def test_sq_bottleneck_host_surface():
     names = [n for n, _, _ in _flat_order(m)]
     assert set(names) == {n for n, _ in m.named_parameters()} and len(names) == len(set(names))
     with pytest.raises(NotImplementedError):
-        spec["args"]["bottleneck_type"] = "fsq"
+        spec["args"]["bottleneck_type"] = "auto"
         vt.make(spec)
     with pytest.raises(vt.hip.HipError):
         m(torch.zeros(1, 3, 4, 32, 32))
+
+
+def test_fsq_bottleneck_branch_host_surface():
+    """LARPTokenizer(bottleneck_type='fsq') (models/larp_tokenizer.py:219-228): LayerNorm + Linear(768, 6) + FSQ([8,8,8,5,5,5]) + Linear(6, 768);
+    the reference's keys, no engine (composed path), loud errors for the engine-only helpers and for CPU tensors."""
+    cfg = O.make_cfg("tiny", bottleneck_type="fsq")
+    spec = spec_from_cfg(cfg)
+    spec["args"]["bottleneck_type"] = "fsq"
+    m = vt.make(spec)
+    sd = m.state_dict()
+    assert {"fsq_in_linear.weight", "fsq_in_linear.bias", "fsq_out_linear.weight", "fsq_out_linear.bias", "fsq_norm.weight", "fsq_norm.bias"} <= set(sd)
+    assert sd["fsq_in_linear.weight"].shape == (6, 768) and sd["fsq_out_linear.weight"].shape == (768, 6)
+    assert not any(k.startswith("bottleneck.") for k in sd) and m.codebook_size == 64000 and m._engine is None
+    assert set(O.init_state_dict(cfg, seed=3).keys()) == set(sd.keys())
+    from video_tokenizer_amd.optim import FusedAdam
+    with pytest.raises(NotImplementedError):
+        FusedAdam(m, lr=1e-4)
+    with pytest.raises(vt.hip.HipError):
+        m(torch.zeros(1, 3, cfg["frame_num"], cfg["input_size"], cfg["input_size"]))
+    perm = m._head_perm(torch.device("cpu"))
+    C, pt, p = 3, cfg["temporal_patch_size"], cfg["patch_size"]
+    ref_cols = torch.arange(pt * p * p * C).reshape(pt, p, p, C).permute(3, 0, 1, 2).reshape(-1)      # (c, dt, dy, dx) <- (dt, dy, dx, c)
+    assert torch.equal(perm, ref_cols)

@@ -566,3 +566,54 @@ def test_bench_own_launcher_path_on_one_gpu():
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["value"] > 50 and r["config"]["parallelism"] == "dp1"
+
+
+def test_fsq_bottleneck_branch_matches_oracle():
+    """bottleneck_type='fsq' (models/larp_tokenizer.py:219-228, 412-418), composed from the sub-modules' autograd functions: forward and all
+    gradients against the oracle that follows the device's codes; codes that differ from the oracle's free-running ones sit on a rounding boundary."""
+    import video_tokenizer_amd as vt
+    cfg = O.make_cfg("tiny", bottleneck_type="fsq")
+    spec = spec_from_cfg(cfg)
+    spec["args"]["bottleneck_type"] = "fsq"
+    model = vt.make(spec)
+    sd = O.init_state_dict(cfg, seed=7, query_std=1.0)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    B = 2
+    x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 11))
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 12))
+    out = model(x.cuda())
+    assert set(out) == {"pred_frames", "encoded"}                      # what the reference's fsq branch returns
+    (out["pred_frames"] * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    codes = model.last_codes.cpu()
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    free = O.tokenizer_forward(p, cfg, x, "L", emu=True)
+    agree = (free["_codes"] == codes).float().mean().item()
+    lv = torch.tensor([8, 8, 8, 5, 5, 5])
+    bad = (free["_codes"] != codes)
+    if bad.any():                                                      # a flipped code: the bounded value is within bf16 noise of a rounding boundary
+        frac = (free["_bounded"][bad] - torch.floor(free["_bounded"][bad])).detach()
+        assert float((frac - 0.5).abs().max()) < 0.08, float((frac - 0.5).abs().max())
+    assert agree > 0.97, agree
+    assert torch.unique(free["_indices"]).numel() >= 0.25 * free["_indices"].numel()          # spread codes, not a collapsed bottleneck
+    ref = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_codes=codes)
+    (ref["pred_frames"] * w).sum().backward()
+    assert rel(out["pred_frames"].detach().cpu(), ref["pred_frames"].detach()) < 2e-2
+    assert rel(out["encoded"].detach().cpu(), ref["encoded"].detach()) < 2e-2
+    worst = {}
+    for n, q in model.named_parameters():
+        g = p[n].grad
+        assert q.grad is not None and g is not None, n
+        worst[n] = rel(q.grad.cpu(), g)
+    bad = {n: r for n, r in worst.items() if r > 6e-2}
+    assert not bad, bad
+    # encode / decode are differentiable on this branch and agree with forward; indices decode back
+    model.eval()
+    with torch.no_grad():
+        e = model.encode(x.cuda())
+        assert set(e) == {"encoded"} and torch.equal(model.decode(e["encoded"]), model(x.cuda())["pred_frames"])
+        assert rel(model.decode_from_bottleneck(model.last_indices), model.decode(e["encoded"])) < 1e-6
+    z = e["encoded"].clone().requires_grad_(True)
+    model.decode(z).abs().mean().backward()
+    assert z.grad is not None and bool(torch.isfinite(z.grad).all()) and float(z.grad.abs().sum()) > 0

@@ -345,3 +345,40 @@ class FiniteScalarQuantize(torch.autograd.Function):
     def backward(ctx, dcodes, _didx):
         (z,) = ctx.saved_tensors
         return hip.fsq_backward(z, dcodes.contiguous().to(z.dtype), ctx.levels), None
+
+
+class LayerNormRows(torch.autograd.Function):
+    """nn.LayerNorm over the last dim on the LayerNorm kernels (fp32 in, statistics in fp32, bf16-rounded output returned in an
+    fp32 tensor -- what the Linear that follows reads under autocast).  Widths of vt_layernorm_fwd (128 ... 1024)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        hip.require_gpu(x, weight, bias)
+        shp = x.shape
+        x2 = x.contiguous().reshape(-1, shp[-1]).float()
+        y, mean, rstd = hip.layernorm_fwd(x2, weight, bias, eps)
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        return y.float().reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        dyb = hip.cast_rows(dy.contiguous().reshape(x2.shape).float())
+        dx, _, dg, db, _ = hip.layernorm_bwd(dyb, x2, weight, mean, rstd, want_dxsum=False)
+        return dx.reshape(dy.shape), dg, db, None
+
+
+class Unpatchify(torch.autograd.Function):
+    """rows [B * N, C * pt * p * p] in (c, dt, dy, dx) column order -> video [B, C, T, S, S] (the scatter of larp_tokenizer.py:441-454
+    once the head's rows are permuted to that order); backward = the patch gather."""
+
+    @staticmethod
+    def forward(ctx, rows, geom):
+        B, C, T, S, pt, p = geom
+        ctx.geom = geom
+        return hip.unpatchify(rows.contiguous().float(), B, C, T, S, pt, p)
+
+    @staticmethod
+    def backward(ctx, dvideo):
+        B, C, T, S, pt, p = ctx.geom
+        return hip.patchify(dvideo.contiguous().float(), pt, p).float(), None

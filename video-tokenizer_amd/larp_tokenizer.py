@@ -45,8 +45,8 @@ class LARPTokenizer(nn.Module):
                  use_decoder_patch_query_token_type_embed=False, encoder_query_gaussian_init=True, **ignored):
         super().__init__()
         # `ignored`: yaml keys the reference class does not take (e.g. use_pe, cfgs/larp_tokenizer.yaml:75)
-        if bottleneck_type not in ("vq", "sq"):
-            raise NotImplementedError(f"bottleneck_type='{bottleneck_type}': this build implements the 'vq' and 'sq' bottlenecks "
+        if bottleneck_type not in ("vq", "sq", "fsq"):
+            raise NotImplementedError(f"bottleneck_type='{bottleneck_type}': this build implements the 'vq', 'sq' and 'fsq' bottlenecks "
                                       "(pass model.args.bottleneck_type vq); 'auto' builds no bottleneck in the reference either")
         if train_type != "simple":
             raise NotImplementedError("train_type 'mrope' is out of scope")
@@ -127,6 +127,17 @@ class LARPTokenizer(nn.Module):
             # parameter names the fused engine binds (engine.py): in/out projection, codebook
             self._bt_names = {"in_w": "bottleneck.in_linear.weight", "in_b": "bottleneck.in_linear.bias", "out_w": "bottleneck.out_linear.weight",
                               "out_b": "bottleneck.out_linear.bias", "codebook": "bottleneck.regularizer.embedding.weight"}
+        elif bottleneck_type == "fsq":
+            # larp_tokenizer.py:219-228, 412-418: LayerNorm -> Linear(768, 6) -> FSQ([8, 8, 8, 5, 5, 5]) -> Linear(6, 768); `encode` returns
+            # {'encoded'} only (the FSQ indices are dropped there).  Not on the fused engine: forward() composes the sub-modules' own
+            # autograd functions (one vt_stack_forward / backward call per stack, the LayerNorm / GEMM / FSQ / patch kernels in between).
+            from .fsq import FSQ
+            self.fsq_in_linear = nn.Linear(encoder_hidden_size, 6)
+            self.fsq_out_linear = nn.Linear(6, decoder_hidden_size)
+            self.fsq_norm = nn.LayerNorm(encoder_hidden_size)
+            self.bottleneck = FSQ(levels=[8, 8, 8, 5, 5, 5])
+            self.bottleneck_dim, self.codebook_size = 6, self.bottleneck.codebook_size
+            self._bt_names = None
         else:
             # larp_tokenizer.py:225-229: Linear(768, 24) -> VectorQuantizer(196 560 x 24, frozen, cosine) -> Linear(24, 768).  The yaml's
             # `bottleneck` entry is ignored on this branch, as in the reference.  `sq_codebook` (extra keyword of this build): a .npy
@@ -142,7 +153,7 @@ class LARPTokenizer(nn.Module):
         self.final_layer = OutputLayer(decoder_hidden_size, decoder_temporal_patch_size, decoder_patch_size, self.out_channels)
         self.prior_model = None  # the reference never builds one (larp_tokenizer.py:239-241); the trainer reads the attribute
         self.initialize_weights()
-        self._engine = _engine.TokenizerEngine(self)
+        self._engine = _engine.TokenizerEngine(self) if bottleneck_type != "fsq" else None
 
     # ------------------------------------------------------------------------------- init
     def initialize_weights(self):
@@ -252,11 +263,58 @@ class LARPTokenizer(nn.Module):
         """larp_tokenizer.py:489-496: {'pred_frames', 'encoded', **bottleneck outputs}.  Differentiable outputs:
         pred_frames, loss_q, loss_commit, loss_codebook (what the trainer back-propagates,
         trainers/larp_tokenizer_trainer.py:294-333,372)."""
+        if self.bottleneck_type == "fsq":
+            enc = self._fsq_encode(data)
+            return {"pred_frames": self._fsq_decode(enc["encoded"]).contiguous(), **enc}
         pred, losses, encoded, idx, pz, uz, rz, emb, norms = _engine.apply(self._engine, data)
         o = {"indices": idx, "projected_z": pz, "input_norms": norms, "unregularized_z": uz, "emb": emb, "regularized_z": rz, "losses": losses}
         if self.bottleneck_type == "sq":
             self.last_indices = idx     # the reference's 'sq' dict carries no token ids (fsq.py:206); kept here for inspection / tests
         return {"pred_frames": pred, "encoded": encoded, **self._bottleneck_dict(o)}
+
+    # ---- bottleneck_type 'fsq': composed from the sub-modules' own autograd functions (differentiable end to end, also through encode / decode)
+    def _fsq_encode(self, x):
+        """larp_tokenizer.py:400-418"""
+        from .functional import LayerNormRows, Linear
+        if not x.is_cuda:
+            raise hip.HipError("LARPTokenizer: input is on the CPU; this build runs on MI355X only (no CPU fallback)")
+        B = x.shape[0]
+        nv = (x.shape[2] // self.temporal_patch_size) * (x.shape[3] // self.patch_size) ** 2
+        tok = self.x_embedder(x, pos_embed=self.encoder_patch_pe[0, :nv])
+        z = self.encoder(tok, self.encoder_latent_query_embed.unsqueeze(0).expand(B, -1, -1))
+        z = LayerNormRows.apply(z, self.fsq_norm.weight, self.fsq_norm.bias, self.fsq_norm.eps)
+        z = Linear.apply(z, self.fsq_in_linear.weight, self.fsq_in_linear.bias)
+        codes, info = self.bottleneck(z)
+        self.last_indices, self.last_codes = info["indices"], codes.detach()     # the reference drops them (:416); kept for inspection / tests
+        return {"encoded": Linear.apply(codes, self.fsq_out_linear.weight, self.fsq_out_linear.bias)}
+
+    def _head_perm(self, device):
+        """head rows in the patch scatter's (c, dt, dy, dx) order <- the reference's (dt, dy, dx, c) (larp_tokenizer.py:452-453)"""
+        hit = getattr(self, "_head_perm_cache", None)
+        if hit is None or hit.device != device:
+            C, pt, p = self.out_channels, self.decoder_temporal_patch_size, self.decoder_patch_size
+            c, dt, dy, dx = torch.meshgrid(torch.arange(C), torch.arange(pt), torch.arange(p), torch.arange(p), indexing="ij")
+            hit = ((((dt * p + dy) * p + dx) * C + c).reshape(-1)).to(device)
+            self._head_perm_cache = hit
+        return hit
+
+    def _fsq_decode(self, z, num_x_tokens=None):
+        """larp_tokenizer.py:456-469 (:471-482 with fewer query tokens)"""
+        from .functional import LayerNormRows, Linear, Unpatchify
+        if not z.is_cuda:
+            raise hip.HipError("LARPTokenizer.decode: input is on the CPU; no CPU fallback")
+        B = z.shape[0]
+        nv = self.recon_video_token_num if num_x_tokens is None else int(num_x_tokens)
+        dq = self.decoder_patch_query_embed[:, :nv]
+        if self.use_decoder_patch_query_token_type_embed:
+            dq = dq + self.decoder_patch_query_token_type_embed
+        h = self.decoder(z.float() + self.decoder_latent_pe, dq.expand(B, -1, -1))
+        fl = self.final_layer
+        y = LayerNormRows.apply(h, fl.norm_final.weight, fl.norm_final.bias, fl.norm_final.eps)
+        perm = self._head_perm(z.device)
+        rows = Linear.apply(y, fl.linear.weight[perm], fl.linear.bias[perm])
+        T = nv // self.decoder_token_h ** 2 * self.decoder_temporal_patch_size
+        return Unpatchify.apply(rows.reshape(B * nv, -1), (B, self.out_channels, T, self.input_size, self.decoder_temporal_patch_size, self.decoder_patch_size))
 
     def _warn_if_graph_expected(self, who, *tensors):
         """encode / decode on their own are forward-only here (the reference's are ordinary differentiable methods,
@@ -270,7 +328,9 @@ class LARPTokenizer(nn.Module):
                           "model(data) instead.  Wrap the call in torch.no_grad() to silence this.", stacklevel=3)
 
     def encode(self, x):
-        """larp_tokenizer.py:400-428 (vq branch), forward only."""
+        """larp_tokenizer.py:400-428 (vq / sq branches: forward only; fsq: differentiable)."""
+        if self.bottleneck_type == "fsq":
+            return self._fsq_encode(x)
         self._warn_if_graph_expected("encode", x)
         with torch.no_grad():
             return self._encode(x)
@@ -288,7 +348,9 @@ class LARPTokenizer(nn.Module):
         return out
 
     def decode(self, z, num_x_tokens=None):
-        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video.  Forward only."""
+        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video.  Forward only (fsq: differentiable)."""
+        if self.bottleneck_type == "fsq":
+            return self._fsq_decode(z, num_x_tokens)
         self._warn_if_graph_expected("decode", z)
         with torch.no_grad():
             return self._decode(z, num_x_tokens)
@@ -318,6 +380,10 @@ class LARPTokenizer(nn.Module):
         import ctypes
         if not bottleneck_rep.is_cuda:
             raise hip.HipError("LARPTokenizer.decode_from_bottleneck: input is on the CPU; no CPU fallback")
+        if self.bottleneck_type == "fsq":    # (the reference's FSQ has no .decode either; here: indices -> codes -> fsq_out_linear -> decode)
+            from .functional import Linear
+            codes = self.bottleneck.indices_to_codes(bottleneck_rep.contiguous().to(torch.int32))
+            return self._fsq_decode(Linear.apply(codes, self.fsq_out_linear.weight, self.fsq_out_linear.bias))
         eng = self._engine
         B = bottleneck_rep.shape[0]
         st = eng.state_for(B, self.frame_num, self.input_size, bottleneck_rep.device)

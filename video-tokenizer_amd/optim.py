@@ -18,6 +18,9 @@ def flatten_parameters(model):
     buffer).  Parameters keep their identity (only `.data` is re-pointed), so optimizers, state_dict and DDP
     wrappers created before or after keep working.  Idempotent."""
     eng = model._engine
+    if eng is None:
+        raise NotImplementedError("FusedAdam works on the fused engine's flat buffers; this model (bottleneck_type 'fsq') is composed of separate autograd "
+                                  "functions: use torch.optim.Adam")
     if getattr(eng, "flat_param", None) is not None and eng.flat_param.device == next(model.parameters()).device:
         return eng.flat_param
     order = _flat_order(model)
@@ -41,6 +44,9 @@ class FusedAdam:
     trainer uses: step(), zero_grad(set_to_none), state_dict(), load_state_dict(), param_groups[0]['lr']."""
 
     def __init__(self, model, lr=1e-4, betas=(0.5, 0.9), eps=1e-8, weight_decay=0.0, ema_decay=None):
+        if getattr(model, "_engine", None) is None:
+            raise NotImplementedError("FusedAdam works on the fused engine's flat buffers; this model (bottleneck_type 'fsq') is composed of separate "
+                                      "autograd functions: use torch.optim.Adam")
         self.model = model
         self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}]
         self.ema_decay = ema_decay

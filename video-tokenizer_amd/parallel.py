@@ -99,6 +99,9 @@ class DataParallelTokenizer(nn.Module):
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t, src=0, group=process_group)
+        if getattr(module, "_engine", None) is None:
+            raise NotImplementedError("this model does not run on the fused engine (bottleneck_type 'fsq'): its gradients are ordinary .grad tensors, "
+                                      "wrap it in torch.nn.parallel.DistributedDataParallel")
         module._engine.reducer = GradReducer(process_group, bucket_bytes)
 
     def forward(self, *a, **k):
