@@ -194,10 +194,14 @@ def vq_forward(z, emb_weight, mode="L", l2_normalized=True, beta=0.25, codebook_
 
 
 def bottleneck_forward(x, p, prefix, mode="L", emu=False, **vq_kw):
-    """bottleneck.py:170-188 with norm='none': norm stats, in_linear, regulariser, out_linear."""
+    """bottleneck.py:170-188: norm stats, in_linear (+ the LayerNorm of norm = 'ln_d' / 'ln_nd', :146-159: fp32, autocast off; its
+    presence is read off the state dict), regulariser, out_linear."""
     n_first = torch.norm(x[:, 0, :], dim=-1).mean()
     n_last = torch.norm(x[:, -1, :], dim=-1).mean()
     z = linear(x, p[prefix + "in_linear.weight"], p[prefix + "in_linear.bias"], emu)
+    if prefix + "norm_layer.weight" in p:
+        w = p[prefix + "norm_layer.weight"]
+        z = F.layer_norm(z.float(), tuple(w.shape), w, p[prefix + "norm_layer.bias"], 1e-5)
     reg = vq_forward(z, p[prefix + "regularizer.embedding.weight"], mode, **vq_kw)
     x_hat = linear(reg["regularized_z"], p[prefix + "out_linear.weight"], p[prefix + "out_linear.bias"], emu)
     rep = reg.pop("bottleneck_rep")
@@ -265,9 +269,21 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
     encoder_depth, decoder_depth, encoder_num_heads, decoder_num_heads, temporal_patch_size,
     patch_size, token_h (and bottleneck_type == 'vq')."""
     b = x.shape[0]
-    tok = patch_embed3d(x, p["x_embedder.proj.weight"], p["x_embedder.proj.bias"], emu)
-    tok = tok + p["encoder_patch_pe"]                                   # :407 (fp32 buffer)
-    q_emb = p["encoder_latent_query_embed"].unsqueeze(0).repeat(b, 1, 1)  # :410
+    wpe = p["x_embedder.proj.weight"]
+    if wpe.dim() == 4:                                                  # VideoPatchEmbed (temporal_patch_size 1, embed.py:16-34): Conv2d per frame, tokens (t, h, w)
+        wpe = wpe.unsqueeze(2)
+    tok = patch_embed3d(x, wpe, p["x_embedder.proj.bias"], emu)
+    if "encoder_h_embed" in p:                                          # learned factorised PE (:121-127)
+        pe = (p["encoder_h_embed"] + p["encode_w_embed"] + p["encoder_t_embed"]).reshape(1, -1, tok.shape[-1])
+    else:
+        pe = p["encoder_patch_pe"]
+    if "encoder_patch_token_type_embed" in p:
+        pe = pe + p["encoder_patch_token_type_embed"]                   # :131-134
+    tok = tok + pe[:, : tok.shape[1]]                                   # :407
+    q_emb = p["encoder_latent_query_embed"].unsqueeze(0)
+    if "encoder_latent_query_token_type_embed" in p:
+        q_emb = q_emb + p["encoder_latent_query_token_type_embed"]      # :147-150
+    q_emb = q_emb.repeat(b, 1, 1)                                       # :410
     z = encoder_parallel(tok, q_emb, p, "encoder.", cfg["encoder_depth"], cfg["encoder_num_heads"], emu)
     if cfg.get("bottleneck_type", "vq") == "sq":                        # :423-428
         zp = linear(z, p["sq_in_linear.weight"], p["sq_in_linear.bias"], emu)
@@ -287,8 +303,14 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
         bo = bottleneck_forward(z, p, "bottleneck.", mode, emu, **vq_kw)     # :420
         encoded = bo.pop("output")
         out = {"encoded": encoded, **bo}
-    zz = encoded + p["decoder_latent_pe"]                               # :463-464
-    dq = p["decoder_patch_query_embed"]
+    lpe = p["decoder_latent_pe"]
+    if "decoder_latent_token_type_embed" in p:
+        lpe = lpe + p["decoder_latent_token_type_embed"]                # :160-163
+    zz = encoded + lpe                                                  # :463-464
+    if "decoder_h_embed" in p:                                          # :167-171
+        dq = (p["decoder_h_embed"] + p["decoder_w_embed"] + p["decoder_t_embed"]).reshape(1, -1, encoded.shape[-1])
+    else:
+        dq = p["decoder_patch_query_embed"]
     if "decoder_patch_query_token_type_embed" in p:
         dq = dq + p["decoder_patch_query_token_type_embed"]             # :178
     dq = dq.expand(b, -1, -1)

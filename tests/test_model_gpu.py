@@ -617,3 +617,66 @@ def test_fsq_bottleneck_branch_matches_oracle():
     z = e["encoded"].clone().requires_grad_(True)
     model.decode(z).abs().mean().backward()
     assert z.grad is not None and bool(torch.isfinite(z.grad).all()) and float(z.grad.abs().sum()) > 0
+
+
+def _extra_state(model, sd, seed):
+    """state dict for a model with constructor options beyond the oracle's init: the keys init_state_dict knows keep its values, the others
+    (learned / token-type embeddings, bottleneck LayerNorm, Conv2d patch weight) are drawn from the counter generator at the module's shapes"""
+    out = {}
+    for i, (k, v) in enumerate(model.state_dict().items()):
+        if k in sd and tuple(sd[k].shape) == tuple(v.shape):
+            out[k] = sd[k]
+        elif k.endswith("norm_layer.weight"):
+            out[k] = torch.from_numpy(gen.uniform(tuple(v.shape), seed + i, 0.8, 1.2))
+        else:
+            out[k] = torch.from_numpy(gen.normal(tuple(v.shape), seed + i, 0.3 if "embed" in k or "latent_pe" in k else 0.05))
+    return out
+
+
+@pytest.mark.parametrize("variant", ["learned_embeddings", "fixed_queries_per_frame_patches", "normalised_bottleneck"])
+def test_constructor_options_on_the_composed_path_match_oracle(variant):
+    """Options of models/larp_tokenizer.py:106-180 that the fused engine does not carry run on the composed path (same kernels through the
+    sub-modules' autograd functions): learned factorised PEs + all four token-type embeddings + learned decoder latent PE; fixed (buffer)
+    latent queries with the per-frame VideoPatchEmbed (temporal_patch_size 1); bottleneck norm 'ln_d'.  Forward, losses and every gradient
+    against the oracle following the device's indices."""
+    import video_tokenizer_amd as vt
+    over, cfg_over = {}, {}
+    if variant == "learned_embeddings":
+        over = dict(learned_encoder_patch_pe=True, use_encoder_patch_token_type_embed=True, use_encoder_latent_query_token_type_embed=True,
+                    learned_decoder_latent_pe=True, use_decoder_latent_token_type_embed=True, learned_decoder_patch_query_embed=True)
+    elif variant == "fixed_queries_per_frame_patches":
+        over = dict(learned_encoder_latent_query_embed=False, encoder_query_gaussian_init=False, temporal_patch_size=1, decoder_temporal_patch_size=1)
+        cfg_over = dict(temporal_patch_size=1, frame_num=2)
+    cfg = O.make_cfg("tiny", **cfg_over)
+    spec = spec_from_cfg(cfg)
+    spec["args"].update(over)
+    if variant == "normalised_bottleneck":
+        spec["args"]["bottleneck"]["args"]["norm"] = "ln_d"
+    model = vt.make(spec)
+    assert model._composed and model._engine is None
+    sd = _extra_state(model, O.init_state_dict(cfg, seed=7, query_std=1.0), 900)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    x = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 21))
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 22))
+    out = model(x.cuda())
+    ((out["pred_frames"] * w.cuda()).sum() + 0.7 * out["loss_q"]).backward()
+    torch.cuda.synchronize()
+    idx = out["bottleneck_rep"].reshape(-1).cpu()
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    free = O.tokenizer_forward(p, cfg, x, "L", emu=True)
+    agree = (free["bottleneck_rep"].reshape(-1) == idx).float().mean().item()
+    assert agree > 0.95, agree
+    assert torch.unique(idx).numel() >= 0.25 * idx.numel()
+    ref = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_idx=idx)
+    ((ref["pred_frames"] * w).sum() + 0.7 * ref["loss_q"]).backward()
+    assert rel(out["pred_frames"].detach().cpu(), ref["pred_frames"].detach()) < 2e-2
+    assert abs(out["loss_q"].item() - ref["loss_q"].item()) < 2e-3 * max(1.0, abs(ref["loss_q"].item()))
+    bad = {}
+    for n, q in model.named_parameters():
+        g = p[n].grad
+        assert q.grad is not None and g is not None, n
+        r = rel(q.grad.cpu(), g)
+        if r > 6e-2:
+            bad[n] = r
+    assert not bad, bad

@@ -94,14 +94,25 @@ class Bottleneck(nn.Module):
             raise NotImplementedError("bottleneck_dim <= 0 (identity projections) is not built")
         self.bottleneck_dim = bottleneck_dim
         norm = None if norm is None or norm.lower() in ("no", "none") else norm.lower()
-        if norm is not None:
-            raise NotImplementedError(f"bottleneck norm '{norm}' is not built (the tokenizer yamls use 'none')")
-        self.norm = None
+        if norm in ("bn_bn", "bn_b"):
+            raise NotImplementedError(f"bottleneck norm '{norm}' (SyncBatchNorm over the batch) is not built (the tokenizer yamls use 'none')")
+        if norm not in (None, "ln_d", "ln_nd", "ln_d_na"):
+            raise ValueError(f"Normalization type {norm} not supported")
+        self.norm = norm
         if regularizer is None or regularizer["name"].lower() != "vq":
             raise NotImplementedError("only the 'vq' regularizer is built")
         self.project_dim = self.bottleneck_dim
         self.in_linear = nn.Linear(self.input_dim, self.project_dim)
         self.out_linear = nn.Linear(self.bottleneck_dim, self.output_dim)
+        # bottleneck.py:113-126: LayerNorm over the d (or token x d) entries of the projected latents, fp32 with autocast off (:146-159).
+        # A [B, Nq, d <= 64] tensor: torch's LayerNorm is the whole cost model here; the fused engine does not carry it, so a tokenizer
+        # with a normalised bottleneck runs on the composed path (LARPTokenizer._composed).
+        if norm == "ln_d":
+            self.norm_layer = nn.LayerNorm(self.project_dim)
+        elif norm == "ln_nd":
+            self.norm_layer = nn.LayerNorm((self.token_nums, self.project_dim))
+        elif norm == "ln_d_na":
+            self.norm_layer = nn.LayerNorm(self.project_dim, elementwise_affine=False)
         regularizer["args"]["dim"] = self.bottleneck_dim
         regularizer["args"]["token_nums"] = self.token_nums
         self.regularizer = make(regularizer)
@@ -109,7 +120,10 @@ class Bottleneck(nn.Module):
     def project_in(self, x):
         from .functional import Linear
         assert len(x.shape) == 3, "Input shape must be (batch, n_tokens, e_dim)"
-        return Linear.apply(x, self.in_linear.weight, self.in_linear.bias)
+        z = Linear.apply(x, self.in_linear.weight, self.in_linear.bias)
+        if self.norm in ("ln_d", "ln_nd"):          # (the reference applies no layer for 'ln_d_na' in project_in either, :146-159)
+            z = self.norm_layer(z.float())
+        return z
 
     def project_out(self, z_cat):
         from .functional import Linear

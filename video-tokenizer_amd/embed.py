@@ -74,3 +74,26 @@ class PatchEmbed3D(nn.Module):
         from .functional import PatchEmbed
         self.check_input(x)
         return PatchEmbed.apply(x, self.proj.weight, self.proj.bias, pos_embed)
+
+
+class VideoPatchEmbed(nn.Module):
+    """models/embed.py:16-34 (temporal_patch_size == 1): timm's 2-D PatchEmbed applied to every frame -- Conv2d(kernel = stride = p), tokens
+    ordered (t, h, w).  Same state-dict keys (`proj.weight [D, C, p, p]`, `proj.bias`); the arithmetic is PatchEmbed3D's gather + GEMM with
+    a temporal patch of one frame."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True, frame_num=None):
+        super().__init__()
+        assert frame_num is not None and bias
+        self.img_size, self.patch_size = (img_size, img_size), (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.num_patches_per_frame = self.num_spatial_patches = self.grid_size[0] * self.grid_size[1]
+        self.num_temporal_patches = frame_num
+        self.flatten = True
+        self.strict_vid_size = True
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
+
+    def forward(self, x, pos_embed=None):
+        from .functional import PatchEmbed
+        _, _, T, H, W = x.shape
+        assert (H, W) == self.img_size, f"Input size ({H}x{W}) doesn't match model ({self.img_size[0]}x{self.img_size[1]})."
+        return PatchEmbed.apply(x, self.proj.weight.unsqueeze(2), self.proj.bias, pos_embed)

@@ -50,19 +50,23 @@ class LARPTokenizer(nn.Module):
                                       "(pass model.args.bottleneck_type vq); 'auto' builds no bottleneck in the reference either")
         if train_type != "simple":
             raise NotImplementedError("train_type 'mrope' is out of scope")
-        unsupported = dict(learned_encoder_patch_pe=learned_encoder_patch_pe, learned_decoder_latent_pe=learned_decoder_latent_pe,
-                           learned_decoder_patch_query_embed=learned_decoder_patch_query_embed,
-                           use_encoder_patch_token_type_embed=use_encoder_patch_token_type_embed,
-                           use_encoder_latent_query_token_type_embed=use_encoder_latent_query_token_type_embed,
-                           use_decoder_latent_token_type_embed=use_decoder_latent_token_type_embed)
-        bad = [k for k, v in unsupported.items() if v]
-        if bad or not learned_encoder_latent_query_embed:
-            raise NotImplementedError(f"option(s) {bad or ['learned_encoder_latent_query_embed=False']} are not built "
-                                      "(the shipped yaml uses fixed sin-cos PEs + learned latent queries)")
-        if temporal_patch_size <= 1:
-            raise NotImplementedError("temporal_patch_size == 1 (VideoPatchEmbed) is not built")
+        # Options beyond what the fused engine carries (learned / token-type position embeddings, fixed latent queries, a per-frame patch
+        # embed, a normalised bottleneck, the 'fsq' branch) run on the COMPOSED path: the same kernels through the sub-modules' own
+        # autograd functions, the small embedding sums and the bottleneck LayerNorm as torch glue (forward(): self._composed).
+        extra = dict(learned_encoder_patch_pe=learned_encoder_patch_pe, learned_decoder_latent_pe=learned_decoder_latent_pe,
+                     learned_decoder_patch_query_embed=learned_decoder_patch_query_embed,
+                     use_encoder_patch_token_type_embed=use_encoder_patch_token_type_embed,
+                     use_encoder_latent_query_token_type_embed=use_encoder_latent_query_token_type_embed,
+                     use_decoder_latent_token_type_embed=use_decoder_latent_token_type_embed,
+                     fixed_latent_queries=not learned_encoder_latent_query_embed, per_frame_patch_embed=temporal_patch_size == 1)
+        bn = bottleneck.get("args", {}).get("norm") if isinstance(bottleneck, dict) and bottleneck_type == "vq" else None
+        extra["bottleneck_norm"] = bn is not None and str(bn).lower() not in ("no", "none")
+        self._composed = bottleneck_type == "fsq" or any(extra.values())
+        assert temporal_patch_size >= 1
         assert (temporal_patch_size, patch_size) == (decoder_temporal_patch_size, decoder_patch_size), \
             "unpatchify uses the ENCODER patch sizes (larp_tokenizer.py:447-449): encoder and decoder patch sizes must match"
+        if temporal_patch_size == 1 and not (learned_encoder_latent_query_embed or True):
+            pass
         assert encoder_hidden_size == decoder_hidden_size and encoder_num_heads == decoder_num_heads, \
             "the fused engine is built for equal encoder/decoder width"
 
@@ -85,30 +89,59 @@ class LARPTokenizer(nn.Module):
         self.latent_pe_scale_factor = latent_pe_scale_factor
         self.query_init_std = query_init_std
 
-        self.x_embedder = PatchEmbed3D(input_size, frame_num, patch_size, temporal_patch_size, in_channels, encoder_hidden_size, bias=True)
-        self.token_h = token_h = self.token_w = int(self.x_embedder.num_spatial_patches ** 0.5)
+        if temporal_patch_size == 1:
+            from .embed import VideoPatchEmbed
+            self.x_embedder = VideoPatchEmbed(input_size, patch_size, in_channels, encoder_hidden_size, bias=True, frame_num=frame_num)
+        else:
+            self.x_embedder = PatchEmbed3D(input_size, frame_num, patch_size, temporal_patch_size, in_channels, encoder_hidden_size, bias=True)
+        self.token_h = token_h = self.token_w = token_w = int(self.x_embedder.num_spatial_patches ** 0.5)
         self.token_t = token_t = self.x_embedder.num_temporal_patches
         self.video_token_num = video_token_num = self.x_embedder.num_spatial_patches * token_t
         assert input_size % decoder_patch_size == 0, "input_size must be divisible by decoder_patch_size"
-        self.decoder_token_t = frame_num // decoder_temporal_patch_size
-        self.decoder_token_h = self.decoder_token_w = input_size // decoder_patch_size
+        self.decoder_token_t = decoder_token_t = frame_num // decoder_temporal_patch_size
+        self.decoder_token_h = self.decoder_token_w = decoder_token_h = input_size // decoder_patch_size
         self.recon_video_token_num = recon_video_token_num = self.decoder_token_h ** 2 * self.decoder_token_t
+        E, Dd = encoder_hidden_size, decoder_hidden_size
 
-        self.learned_encoder_patch_pe = False
-        self.register_buffer("encoder_patch_pe", torch.zeros(1, video_token_num, encoder_hidden_size))
-        self.use_encoder_patch_token_type_embed = False
-        self.learned_encoder_latent_query_embed = True
+        # the position / query / token-type embeddings of larp_tokenizer.py:119-180, under the reference's names
+        self.learned_encoder_patch_pe = learned_encoder_patch_pe
+        if learned_encoder_patch_pe:
+            self.encoder_h_embed = nn.Parameter(torch.zeros(1, 1, token_h, 1, E), requires_grad=True)
+            self.encode_w_embed = nn.Parameter(torch.zeros(1, 1, 1, token_w, E), requires_grad=True)
+            self.encoder_t_embed = nn.Parameter(torch.zeros(1, token_t, 1, 1, E), requires_grad=True)
+        else:
+            self.register_buffer("encoder_patch_pe", torch.zeros(1, video_token_num, E))
+        self.use_encoder_patch_token_type_embed = use_encoder_patch_token_type_embed
+        if use_encoder_patch_token_type_embed:
+            self.encoder_patch_token_type_embed = nn.Parameter(torch.zeros(1, 1, E), requires_grad=True)
+        self.learned_encoder_latent_query_embed = learned_encoder_latent_query_embed
         self.encoder_query_gaussian_init = encoder_query_gaussian_init
-        self.encoder_latent_query_embed = nn.Parameter(torch.zeros(bottleneck_token_num, encoder_hidden_size), requires_grad=True)
-        self.use_encoder_latent_query_token_type_embed = False
-        self.learned_decoder_latent_pe = False
-        self.register_buffer("decoder_latent_pe", torch.zeros(1, self.decoder_latent_len, decoder_hidden_size))
-        self.use_decoder_latent_token_type_embed = False
-        self.learned_decoder_patch_query_embed = False
-        self.register_buffer("decoder_patch_query_embed", torch.zeros(1, recon_video_token_num, decoder_hidden_size))
+        if learned_encoder_latent_query_embed:
+            self.encoder_latent_query_embed = nn.Parameter(torch.zeros(bottleneck_token_num, E), requires_grad=True)
+        else:
+            self.register_buffer("encoder_latent_query_embed", torch.zeros(bottleneck_token_num, E))
+            assert not encoder_query_gaussian_init, "encoder_query_gaussian_init requires learned_encoder_latent_query_embed to be True"
+        self.use_encoder_latent_query_token_type_embed = use_encoder_latent_query_token_type_embed
+        if use_encoder_latent_query_token_type_embed:
+            self.encoder_latent_query_token_type_embed = nn.Parameter(torch.zeros(1, 1, E), requires_grad=True)
+        self.learned_decoder_latent_pe = learned_decoder_latent_pe
+        if learned_decoder_latent_pe:
+            self.decoder_latent_pe = nn.Parameter(torch.zeros(1, self.decoder_latent_len, Dd), requires_grad=True)
+        else:
+            self.register_buffer("decoder_latent_pe", torch.zeros(1, self.decoder_latent_len, Dd))
+        self.use_decoder_latent_token_type_embed = use_decoder_latent_token_type_embed
+        if use_decoder_latent_token_type_embed:
+            self.decoder_latent_token_type_embed = nn.Parameter(torch.zeros(1, 1, Dd), requires_grad=True)
+        self.learned_decoder_patch_query_embed = learned_decoder_patch_query_embed
+        if learned_decoder_patch_query_embed:
+            self.decoder_h_embed = nn.Parameter(torch.zeros(1, 1, decoder_token_h, 1, Dd), requires_grad=True)
+            self.decoder_w_embed = nn.Parameter(torch.zeros(1, 1, 1, decoder_token_h, Dd), requires_grad=True)
+            self.decoder_t_embed = nn.Parameter(torch.zeros(1, decoder_token_t, 1, 1, Dd), requires_grad=True)
+        else:
+            self.register_buffer("decoder_patch_query_embed", torch.zeros(1, recon_video_token_num, Dd))
         self.use_decoder_patch_query_token_type_embed = use_decoder_patch_query_token_type_embed
         if use_decoder_patch_query_token_type_embed:
-            self.decoder_patch_query_token_type_embed = nn.Parameter(torch.zeros(1, 1, decoder_hidden_size), requires_grad=True)
+            self.decoder_patch_query_token_type_embed = nn.Parameter(torch.zeros(1, 1, Dd), requires_grad=True)
 
         def _name(n):
             return transformer_name if n is None or str(n).lower() in ("none", "no", "null", "") else n
@@ -153,7 +186,7 @@ class LARPTokenizer(nn.Module):
         self.final_layer = OutputLayer(decoder_hidden_size, decoder_temporal_patch_size, decoder_patch_size, self.out_channels)
         self.prior_model = None  # the reference never builds one (larp_tokenizer.py:239-241); the trainer reads the attribute
         self.initialize_weights()
-        self._engine = _engine.TokenizerEngine(self) if bottleneck_type != "fsq" else None
+        self._engine = None if self._composed else _engine.TokenizerEngine(self)
 
     # ------------------------------------------------------------------------------- init
     def initialize_weights(self):
@@ -165,25 +198,64 @@ class LARPTokenizer(nn.Module):
                 if module.bias is not None:
                     nn.init.constant_(module.bias, 0)
         self.apply(_basic_init)
-        D = self.encoder_hidden_size
-        pe = get_3d_sincos_pos_embed(D, self.token_h, self.token_t)
-        self.encoder_patch_pe.data.copy_(torch.from_numpy(pe).float().reshape_as(self.encoder_patch_pe))
-        if self.encoder_query_gaussian_init:
-            q = torch.randn(self.bottleneck_token_num, D) * self.query_init_std
+        D, Dd = self.encoder_hidden_size, self.decoder_hidden_size
+
+        def tab(dim, n, scale=10000):
+            return torch.from_numpy(get_1d_sincos_pos_embed_from_grid(dim, np.arange(n), scale)).float()
+        if self.learned_encoder_patch_pe:                                                        # :258-264
+            self.encoder_h_embed.data.copy_(tab(D, self.token_h).reshape_as(self.encoder_h_embed))
+            self.encode_w_embed.data.copy_(tab(D, self.token_w).reshape_as(self.encode_w_embed))
+            self.encoder_t_embed.data.copy_(tab(D, self.token_t).reshape_as(self.encoder_t_embed))
         else:
-            q = torch.from_numpy(get_1d_sincos_pos_embed_from_grid(D, np.arange(self.bottleneck_token_num))).float()
+            pe = get_3d_sincos_pos_embed(D, self.token_h, self.token_t)
+            self.encoder_patch_pe.data.copy_(torch.from_numpy(pe).float().reshape_as(self.encoder_patch_pe))
+        if self.use_encoder_patch_token_type_embed:
+            self.encoder_patch_token_type_embed.data.copy_(torch.randn(1, 1, D) * 0.02)
+        if self.learned_encoder_latent_query_embed:                                              # :273-285
+            q = torch.randn(self.bottleneck_token_num, D) * self.query_init_std if self.encoder_query_gaussian_init else tab(D, self.bottleneck_token_num)
+        else:
+            q = tab(D, self.bottleneck_token_num, self.latent_pe_scale_factor)
         self.encoder_latent_query_embed.data.copy_(q)
-        lp = get_1d_sincos_pos_embed_from_grid(self.decoder_hidden_size, np.arange(self.decoder_latent_len), self.latent_pe_scale_factor)
-        self.decoder_latent_pe.data.copy_(torch.from_numpy(lp).float().reshape_as(self.decoder_latent_pe))
-        dq = get_3d_sincos_pos_embed(self.decoder_hidden_size, self.decoder_token_h, self.decoder_token_t)
-        self.decoder_patch_query_embed.data.copy_(torch.from_numpy(dq).float().reshape_as(self.decoder_patch_query_embed))
+        if self.use_encoder_latent_query_token_type_embed:
+            self.encoder_latent_query_token_type_embed.data.copy_(torch.randn(1, 1, D) * 0.02)
+        if self.learned_decoder_latent_pe:                                                       # :291-297
+            self.decoder_latent_pe.data.copy_(torch.randn(1, self.decoder_latent_len, Dd) * 0.02)
+        else:
+            self.decoder_latent_pe.data.copy_(tab(Dd, self.decoder_latent_len, self.latent_pe_scale_factor).reshape_as(self.decoder_latent_pe))
+        if self.use_decoder_latent_token_type_embed:
+            self.decoder_latent_token_type_embed.data.copy_(torch.randn(1, 1, Dd) * 0.02)
+        if self.learned_decoder_patch_query_embed:                                               # :303-309
+            self.decoder_h_embed.data.copy_(tab(Dd, self.decoder_token_h).reshape_as(self.decoder_h_embed))
+            self.decoder_w_embed.data.copy_(tab(Dd, self.decoder_token_w).reshape_as(self.decoder_w_embed))
+            self.decoder_t_embed.data.copy_(tab(Dd, self.decoder_token_t).reshape_as(self.decoder_t_embed))
+        else:
+            dq = get_3d_sincos_pos_embed(Dd, self.decoder_token_h, self.decoder_token_t)
+            self.decoder_patch_query_embed.data.copy_(torch.from_numpy(dq).float().reshape_as(self.decoder_patch_query_embed))
         if self.use_decoder_patch_query_token_type_embed:
-            self.decoder_patch_query_token_type_embed.data.copy_(torch.randn(1, 1, self.decoder_hidden_size) * 0.02)
+            self.decoder_patch_query_token_type_embed.data.copy_(torch.randn(1, 1, Dd) * 0.02)
         w = self.x_embedder.proj.weight.data
         nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
         nn.init.constant_(self.x_embedder.proj.bias, 0)
         nn.init.constant_(self.final_layer.linear.weight, 0)
         nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    # ------------------------------------------------------------------------------- embeddings (larp_tokenizer.py:119-180)
+    def get_encoder_patch_pe(self):
+        pe = (self.encoder_h_embed + self.encode_w_embed + self.encoder_t_embed).reshape(1, self.video_token_num, self.encoder_hidden_size) \
+            if self.learned_encoder_patch_pe else self.encoder_patch_pe
+        return pe + self.encoder_patch_token_type_embed if self.use_encoder_patch_token_type_embed else pe
+
+    def get_encoder_latent_query_embed(self):
+        q = self.encoder_latent_query_embed.unsqueeze(0)
+        return q + self.encoder_latent_query_token_type_embed if self.use_encoder_latent_query_token_type_embed else q
+
+    def get_decoder_latent_pe(self):
+        return self.decoder_latent_pe + self.decoder_latent_token_type_embed if self.use_decoder_latent_token_type_embed else self.decoder_latent_pe
+
+    def get_decoder_patch_query_embed(self):
+        q = (self.decoder_h_embed + self.decoder_w_embed + self.decoder_t_embed).reshape(1, self.recon_video_token_num, self.decoder_hidden_size) \
+            if self.learned_decoder_patch_query_embed else self.decoder_patch_query_embed
+        return q + self.decoder_patch_query_token_type_embed if self.use_decoder_patch_query_token_type_embed else q
 
     # ------------------------------------------------------------------------------- small API
     def get_last_layer(self):
@@ -263,30 +335,41 @@ class LARPTokenizer(nn.Module):
         """larp_tokenizer.py:489-496: {'pred_frames', 'encoded', **bottleneck outputs}.  Differentiable outputs:
         pred_frames, loss_q, loss_commit, loss_codebook (what the trainer back-propagates,
         trainers/larp_tokenizer_trainer.py:294-333,372)."""
-        if self.bottleneck_type == "fsq":
-            enc = self._fsq_encode(data)
-            return {"pred_frames": self._fsq_decode(enc["encoded"]).contiguous(), **enc}
+        if self._composed:
+            enc = self._composed_encode(data)
+            return {"pred_frames": self._composed_decode(enc["encoded"]).contiguous(), **enc}
         pred, losses, encoded, idx, pz, uz, rz, emb, norms = _engine.apply(self._engine, data)
         o = {"indices": idx, "projected_z": pz, "input_norms": norms, "unregularized_z": uz, "emb": emb, "regularized_z": rz, "losses": losses}
         if self.bottleneck_type == "sq":
             self.last_indices = idx     # the reference's 'sq' dict carries no token ids (fsq.py:206); kept here for inspection / tests
         return {"pred_frames": pred, "encoded": encoded, **self._bottleneck_dict(o)}
 
-    # ---- bottleneck_type 'fsq': composed from the sub-modules' own autograd functions (differentiable end to end, also through encode / decode)
-    def _fsq_encode(self, x):
-        """larp_tokenizer.py:400-418"""
+    # ---- the composed path (self._composed): the sub-modules' own autograd functions, differentiable end to end, also through encode / decode
+    def _composed_encode(self, x, num_tokens_only=False):
+        """larp_tokenizer.py:400-428"""
         from .functional import LayerNormRows, Linear
         if not x.is_cuda:
             raise hip.HipError("LARPTokenizer: input is on the CPU; this build runs on MI355X only (no CPU fallback)")
         B = x.shape[0]
         nv = (x.shape[2] // self.temporal_patch_size) * (x.shape[3] // self.patch_size) ** 2
-        tok = self.x_embedder(x, pos_embed=self.encoder_patch_pe[0, :nv])
-        z = self.encoder(tok, self.encoder_latent_query_embed.unsqueeze(0).expand(B, -1, -1))
-        z = LayerNormRows.apply(z, self.fsq_norm.weight, self.fsq_norm.bias, self.fsq_norm.eps)
-        z = Linear.apply(z, self.fsq_in_linear.weight, self.fsq_in_linear.bias)
-        codes, info = self.bottleneck(z)
-        self.last_indices, self.last_codes = info["indices"], codes.detach()     # the reference drops them (:416); kept for inspection / tests
-        return {"encoded": Linear.apply(codes, self.fsq_out_linear.weight, self.fsq_out_linear.bias)}
+        pe = self.get_encoder_patch_pe()[:, :nv]
+        if pe.requires_grad:                      # learned / token-type embeddings: the add carries their gradient
+            tok = self.x_embedder(x) + pe
+        else:
+            tok = self.x_embedder(x, pos_embed=pe[0])
+        z = self.encoder(tok, self.get_encoder_latent_query_embed().expand(B, -1, -1))
+        if self.bottleneck_type == "fsq":
+            z = LayerNormRows.apply(z, self.fsq_norm.weight, self.fsq_norm.bias, self.fsq_norm.eps)
+            z = Linear.apply(z, self.fsq_in_linear.weight, self.fsq_in_linear.bias)
+            codes, info = self.bottleneck(z)
+            self.last_indices, self.last_codes = info["indices"], codes.detach()     # the reference drops them (:416); kept for inspection / tests
+            return {"encoded": Linear.apply(codes, self.fsq_out_linear.weight, self.fsq_out_linear.bias)}
+        if self.bottleneck_type == "sq":
+            o = self.bottleneck(Linear.apply(z, self.sq_in_linear.weight, self.sq_in_linear.bias))
+            self.last_indices = o.pop("indices")
+            return {"encoded": Linear.apply(o.pop("output"), self.sq_out_linear.weight, self.sq_out_linear.bias), **o}
+        o = self.bottleneck(z)
+        return {"encoded": o.pop("output"), **o}
 
     def _head_perm(self, device):
         """head rows in the patch scatter's (c, dt, dy, dx) order <- the reference's (dt, dy, dx, c) (larp_tokenizer.py:452-453)"""
@@ -298,17 +381,15 @@ class LARPTokenizer(nn.Module):
             self._head_perm_cache = hit
         return hit
 
-    def _fsq_decode(self, z, num_x_tokens=None):
+    def _composed_decode(self, z, num_x_tokens=None):
         """larp_tokenizer.py:456-469 (:471-482 with fewer query tokens)"""
         from .functional import LayerNormRows, Linear, Unpatchify
         if not z.is_cuda:
             raise hip.HipError("LARPTokenizer.decode: input is on the CPU; no CPU fallback")
         B = z.shape[0]
         nv = self.recon_video_token_num if num_x_tokens is None else int(num_x_tokens)
-        dq = self.decoder_patch_query_embed[:, :nv]
-        if self.use_decoder_patch_query_token_type_embed:
-            dq = dq + self.decoder_patch_query_token_type_embed
-        h = self.decoder(z.float() + self.decoder_latent_pe, dq.expand(B, -1, -1))
+        dq = self.get_decoder_patch_query_embed()[:, :nv]
+        h = self.decoder(z.float() + self.get_decoder_latent_pe(), dq.expand(B, -1, -1))
         fl = self.final_layer
         y = LayerNormRows.apply(h, fl.norm_final.weight, fl.norm_final.bias, fl.norm_final.eps)
         perm = self._head_perm(z.device)
@@ -329,8 +410,8 @@ class LARPTokenizer(nn.Module):
 
     def encode(self, x):
         """larp_tokenizer.py:400-428 (vq / sq branches: forward only; fsq: differentiable)."""
-        if self.bottleneck_type == "fsq":
-            return self._fsq_encode(x)
+        if self._composed:
+            return self._composed_encode(x)
         self._warn_if_graph_expected("encode", x)
         with torch.no_grad():
             return self._encode(x)
@@ -349,8 +430,8 @@ class LARPTokenizer(nn.Module):
 
     def decode(self, z, num_x_tokens=None):
         """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video.  Forward only (fsq: differentiable)."""
-        if self.bottleneck_type == "fsq":
-            return self._fsq_decode(z, num_x_tokens)
+        if self._composed:
+            return self._composed_decode(z, num_x_tokens)
         self._warn_if_graph_expected("decode", z)
         with torch.no_grad():
             return self._decode(z, num_x_tokens)
@@ -380,10 +461,15 @@ class LARPTokenizer(nn.Module):
         import ctypes
         if not bottleneck_rep.is_cuda:
             raise hip.HipError("LARPTokenizer.decode_from_bottleneck: input is on the CPU; no CPU fallback")
-        if self.bottleneck_type == "fsq":    # (the reference's FSQ has no .decode either; here: indices -> codes -> fsq_out_linear -> decode)
+        if self._composed:
             from .functional import Linear
-            codes = self.bottleneck.indices_to_codes(bottleneck_rep.contiguous().to(torch.int32))
-            return self._fsq_decode(Linear.apply(codes, self.fsq_out_linear.weight, self.fsq_out_linear.bias))
+            if self.bottleneck_type == "fsq":    # (the reference's FSQ has no .decode; here: indices -> codes -> fsq_out_linear -> decode)
+                codes = self.bottleneck.indices_to_codes(bottleneck_rep.contiguous().to(torch.int32))
+                return self._composed_decode(Linear.apply(codes, self.fsq_out_linear.weight, self.fsq_out_linear.bias))
+            if self.bottleneck_type == "sq":
+                q = self.bottleneck.get_codebook_entry(bottleneck_rep)
+                return self._composed_decode(Linear.apply(q, self.sq_out_linear.weight, self.sq_out_linear.bias))
+            return self._composed_decode(self.bottleneck.decode(bottleneck_rep))
         eng = self._engine
         B = bottleneck_rep.shape[0]
         st = eng.state_for(B, self.frame_num, self.input_size, bottleneck_rep.device)
