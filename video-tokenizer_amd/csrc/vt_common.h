@@ -183,4 +183,21 @@ struct RowMap {
         return grp ? (r / grp) * stride + off + (r % grp) : r;
     }
 };
+
+// ---- library-private (not part of the C ABI): deferred partial-sum reductions of the tokenizer engine ----------------------
+// The backward of a block leaves three sets of per-slab partial sums (fc1 bias gradient out of the gelu' epilogue, the two
+// LayerNorm backward kernels' dgamma / dbeta / column sums).  Reducing each with its own launch costs a ~4.8 us kernel 82 times
+// per step; the engine queues them and reduces the queue of 4 blocks in ONE launch next to the grouped weight-gradient GEMM.
+struct vtReduceItem {
+    const float* partial;   // [nslab][slab_stride]
+    int nslab, width, nout, lanes;   // lanes = 8 or 32 slab lanes per column: the summation order of the stand-alone reducers
+    int64_t slab_stride;
+    float* o[3];            // o[w][c] = sum_s partial[s * slab_stride + w * width + c]
+};
+#define VT_REDUCE_MAX_GROUP 16
+int vt_reduce_grouped(const vtReduceItem* items, int n, vtStream stream);
+// LayerNorm backward without its reduction: partial sums go to `part` ([grid][3 * dim]); *nslab = grid
+int vt_layernorm_bwd_partials(const void* dy_bf16, const float* x, vtRowMap xmap, const float* gamma, const float* mean, const float* rstd,
+                              const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16, float* part, int* nslab, vtStream stream);
+
 #endif

@@ -93,11 +93,12 @@ struct vtTokenizer {
     // row (L - nk) is a multiple of 64.
     struct LastBlock { int enabled, nk, q_begin, Mk, Mkp; size_t dxa, dxm, du; };
     LastBlock last_enc, last_dec;
-    struct GradSet { size_t dx_out, dx_mid, du, dqkv; };
+    struct GradSet { size_t dx_out, dx_mid, du, dqkv, ln_part1, ln_part2, cs_part; };   // + the block's partial sums awaiting the grouped reduction
     static constexpr int WG_BATCH = 4;
     GradSet gs[WG_BATCH + 1];
     // host-side state of an in-flight backward
     std::vector<vtGemmTN> pending;
+    std::vector<vtReduceItem> pending_red;   // partial-sum reductions of the same blocks (one grouped launch at the flush)
     int pending_blocks = 0;   // blocks whose wgrads sit in `pending`
     int set_idx = 0;          // gradient set of the block processed next
     int final_through = 0;    // stages [0, final_through) have complete gradients
@@ -179,6 +180,8 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
     for (auto& g : t->gs) {
         g.dx_out = a.take(Mp * D * 2); g.dx_mid = a.take(Mp * D * 2);
         g.du = a.take(Mp * t->D4 * 2); g.dqkv = a.take(Mp * t->D3 * 2);
+        g.ln_part1 = a.take(vt_layernorm_bwd_workspace_bytes((int)D)); g.ln_part2 = a.take(vt_layernorm_bwd_workspace_bytes((int)D));
+        g.cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);
     }
     t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
     for (int which = 0; which < 2; ++which) {
@@ -451,9 +454,28 @@ static int flush_wgrads(vtTokenizer* t, int stage_done, vtStream s) {
         TRY(vt_gemm_tn_grouped(t->pending.data() + i, n, s));
     }
     t->pending.clear();
+    for (size_t i = 0; i < t->pending_red.size(); i += VT_REDUCE_MAX_GROUP) {
+        const int n = (int)((t->pending_red.size() - i) < VT_REDUCE_MAX_GROUP ? (t->pending_red.size() - i) : VT_REDUCE_MAX_GROUP);
+        TRY(vt_reduce_grouped(t->pending_red.data() + i, n, s));
+    }
+    t->pending_red.clear();
     t->pending_blocks = 0;
     t->final_through = stage_done;
     return VT_OK;
+}
+
+// queue the reduction of a LayerNorm backward's partials / of the gelu' epilogue's column sums
+static void queue_ln_reduce(vtTokenizer* t, const float* part, int nslab, int D, float* dgamma, float* dbeta, float* dxsum) {
+    vtReduceItem q;
+    q.partial = part; q.nslab = nslab; q.width = D; q.nout = dxsum ? 3 : 2; q.lanes = nslab >= 128 ? 32 : 8; q.slab_stride = (int64_t)3 * D;
+    q.o[0] = dgamma; q.o[1] = dbeta; q.o[2] = dxsum;
+    t->pending_red.push_back(q);
+}
+static void queue_slab_sum(vtTokenizer* t, const float* part, int nslab, int width, float* out) {
+    vtReduceItem q;
+    q.partial = part; q.nslab = nslab; q.width = width; q.nout = 1; q.lanes = nslab >= 128 ? 32 : 8; q.slab_stride = width;
+    q.o[0] = out; q.o[1] = q.o[2] = nullptr;
+    t->pending_red.push_back(q);
 }
 
 // Backward of one block.  In: dX (fp32) and gs[set].dx_out (bf16) hold dL/dx_out.  Out: dX holds dL/dx_in and its bf16
@@ -474,15 +496,17 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     // fc2 dgrad fused with GELU': du = (dx_out . W2) * gelu'(u)
     vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, du, D4);
     g.aux = WS(void, b.u); g.ldaux = D4;
-    g.colsum_partial = WS(float, t->cs_part);  // fc1 bias gradient = column sums of du, taken in the epilogue
+    g.colsum_partial = WS(float, g0.cs_part);  // fc1 bias gradient = column sums of du, taken in the epilogue; summed at the flush
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_sum_slabs(WS(float, t->cs_part), (M + 191) / 192, D4, D4, gr.fc1_b, s));
+    queue_slab_sum(t, WS(float, g0.cs_part), (M + 191) / 192, D4, gr.fc1_b);
     // fc1 dgrad
     g = nt(du, D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     // LayerNorm2 backward + residual: dx_mid = dx_out + ln_bwd(dh2) (in place in dX; bf16 copy -> dXm); column sum = proj bias grad
-    TRY(vt_layernorm_bwd(WS(void, t->dh), WS(float, b.x_mid), id, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, M, D, dX, dXm,
-                         gr.norm2_w, gr.norm2_b, gr.proj_b, WS(void, t->ln_ws), s));
+    int nsl = 0;
+    TRY(vt_layernorm_bwd_partials(WS(void, t->dh), WS(float, b.x_mid), id, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, M, D, dX, dXm,
+                                  WS(float, g0.ln_part2), &nsl, s));
+    queue_ln_reduce(t, WS(float, g0.ln_part2), nsl, D, gr.norm2_w, gr.norm2_b, gr.proj_b);
     // proj dgrad
     g = nt(dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
@@ -498,8 +522,9 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     t->pending.push_back(tn(dqkv, D3, WS(void, b.h1), D, Mp, D3, D, gr.qkv_w, D));
     t->pending_blocks++;
     // LayerNorm1 backward + residual: dx_in = dx_mid + ln_bwd(dh) (in place; bf16 copy -> next set's dx_out)
-    TRY(vt_layernorm_bwd(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
-                         gr.norm1_w, gr.norm1_b, prev_bias_grad, WS(void, t->ln_ws), s));
+    TRY(vt_layernorm_bwd_partials(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
+                                  WS(float, g0.ln_part1), &nsl, s));
+    queue_ln_reduce(t, WS(float, g0.ln_part1), nsl, D, gr.norm1_w, gr.norm1_b, prev_bias_grad);
     t->set_idx = (t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1);
     return VT_OK;
 }
@@ -522,13 +547,15 @@ static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb,
     TRY(vt_cast_rows(dX, kmap, Mk, D, dXa, D, s));
     vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, Mk, D4, D, VT_EPI_BF16_DGELU, du, D4);
     g.aux = WS(void, b.u); g.ldaux = D4;
-    g.colsum_partial = WS(float, t->cs_part);
+    g.colsum_partial = WS(float, g0.cs_part);
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_sum_slabs(WS(float, t->cs_part), (Mk + 191) / 192, D4, D4, gr.fc1_b, s));
+    queue_slab_sum(t, WS(float, g0.cs_part), (Mk + 191) / 192, D4, gr.fc1_b);
     g = nt(du, D4, WS(void, b.fc1_wt), D4, Mk, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_layernorm_bwd(WS(void, t->dh), WS(float, b.x_mid), kmap, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, Mk, D, dX, nullptr,
-                         gr.norm2_w, gr.norm2_b, gr.proj_b, WS(void, t->ln_ws), s));
+    int nsl = 0;
+    TRY(vt_layernorm_bwd_partials(WS(void, t->dh), WS(float, b.x_mid), kmap, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, Mk, D, dX, nullptr,
+                                  WS(float, g0.ln_part2), &nsl, s));
+    queue_ln_reduce(t, WS(float, g0.ln_part2), nsl, D, gr.norm2_w, gr.norm2_b, gr.proj_b);
     TRY(vt_cast_rows(dX, kmap, Mk, D, dXm, D, s));
     g = nt(dXm, D, WS(void, b.proj_wt), D, Mk, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
@@ -541,8 +568,9 @@ static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb,
     t->pending.push_back(tn(dXm, D, WS(void, b.o), D, Mkp, D, D, gr.proj_w, D));
     t->pending.push_back(tn(dqkv, D3, WS(void, b.h1), D, Mp, D3, D, gr.qkv_w, D));
     t->pending_blocks++;
-    TRY(vt_layernorm_bwd(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
-                         gr.norm1_w, gr.norm1_b, prev_bias_grad, WS(void, t->ln_ws), s));
+    TRY(vt_layernorm_bwd_partials(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
+                                  WS(float, g0.ln_part1), &nsl, s));
+    queue_ln_reduce(t, WS(float, g0.ln_part1), nsl, D, gr.norm1_w, gr.norm1_b, prev_bias_grad);
     t->set_idx = (t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1);
     return VT_OK;
 }
@@ -565,7 +593,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
             t->pending.clear();
-            t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
+            t->pending_red.clear(); t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
             // ---- head: d_pred -> patch rows (c,dt,dy,dx) -> dgrad / wgrad -> LayerNorm backward into the last Nv rows
             VT_CHECK_ARG(d_pred, "vt_tokenizer_backward: stage 0 needs d_pred");
             TRY(vt_patchify(d_pred, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->dY), s));
@@ -674,6 +702,8 @@ extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
     for (auto& g : t->gs) {
         g.dx_out = a.take(Mp * D * 2); g.dx_mid = a.take(Mp * D * 2);
         g.du = a.take(Mp * t->D4 * 2); g.dqkv = a.take(Mp * t->D3 * 2);
+        g.ln_part1 = a.take(vt_layernorm_bwd_workspace_bytes((int)D)); g.ln_part2 = a.take(vt_layernorm_bwd_workspace_bytes((int)D));
+        g.cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);
     }
     t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
     t->delta = a.take((size_t)B * H * L * 4);
@@ -717,14 +747,15 @@ extern "C" int vt_stack_backward(vtStack* t, const vtBlockTensors* blocks, const
     hipStream_t hs = (hipStream_t)s;
     float* dX = WS(float, t->dX);
     t->pending.clear();
-    t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
+    t->pending_red.clear(); t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
     TRY(copy_d2d(dX, dy, bytes, hs));
     TRY(vt_cast_rows(dX, id, t->M, D, WS(void, t->gs[0].dx_out), D, s));
     TRY(vt_colsum(dX, 0, D, id, t->M, D, grads[depth - 1].fc2_b, WS(void, t->cs_ws), s));
     for (int i = depth - 1; i >= 0; --i) {
         TRY(block_backward(t, t->enc[i], blocks[i], grads[i], WS(float, t->x_enc[i]), i > 0 ? grads[i - 1].fc2_b : nullptr, ws, s));
         if (!need_wgrad) {  // frozen stack (generator-side pass through the discriminator): input gradient only
-            t->pending.clear();
+            t->pending.clear();      // (the parameter gradients of a frozen stack are not wanted either: drop the queued reductions)
+            t->pending_red.clear();
             t->pending_blocks = 0;
         } else if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) {
             TRY(flush_wgrads(t, 0, s));

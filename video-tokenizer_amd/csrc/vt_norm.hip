@@ -176,6 +176,32 @@ static void launch_reduce_partials(const float* partial, int nslab, int64_t slab
     else hipLaunchKernelGGL(reduce_partials_kernel<8>, grid, dim3(256), 0, s, partial, nslab, slab_stride, width, ro);
 }
 
+// several reductions in one launch (blockIdx.z = item); per item the arithmetic of reduce_partials_kernel<lanes>
+struct ReduceGroup {
+    vtReduceItem it[VT_REDUCE_MAX_GROUP];
+};
+__global__ __launch_bounds__(1024) void reduce_grouped_kernel(const ReduceGroup g) {
+    __shared__ float red[32][33];
+    const vtReduceItem& q = g.it[blockIdx.z];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const int w = blockIdx.y;
+    if (w >= q.nout || blockIdx.x * 32 >= q.width) return;      // uniform per workgroup
+    float s = 0.f;
+    if (c < q.width && ty < q.lanes) {
+        const float* p = q.partial + (int64_t)w * q.width + c;
+#pragma unroll 4
+        for (int i = ty; i < q.nslab; i += q.lanes) s += p[(int64_t)i * q.slab_stride];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < q.width) {
+        float t = 0.f;
+        for (int k = 0; k < q.lanes; ++k) t += red[k][tx];
+        q.o[w][c] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // column sums of a [rows, width] matrix (bf16 or fp32, optional row map) -> partial[slab][width]
 // workgroup = 4 waves over one 512-column chunk; lane owns 8 consecutive columns
@@ -335,6 +361,22 @@ __global__ __launch_bounds__(256) void pack_weight_group_kernel(const PackGroup 
 
 }  // namespace
 
+int vt_reduce_grouped(const vtReduceItem* items, int n, vtStream stream) {
+    VT_CHECK_ARG(items && n > 0 && n <= VT_REDUCE_MAX_GROUP, "vt_reduce_grouped: 1..%d items", VT_REDUCE_MAX_GROUP);
+    ReduceGroup g;
+    int wmax = 0, nout = 0;
+    for (int i = 0; i < n; ++i) {
+        g.it[i] = items[i];
+        VT_CHECK_ARG(items[i].partial && items[i].nout >= 1 && items[i].nout <= 3 && (items[i].lanes == 8 || items[i].lanes == 32), "vt_reduce_grouped: bad item %d", i);
+        wmax = items[i].width > wmax ? items[i].width : wmax;
+        nout = items[i].nout > nout ? items[i].nout : nout;
+    }
+    hipLaunchKernelGGL(reduce_grouped_kernel, dim3((wmax + 31) / 32, nout, n), dim3(1024), 0, (hipStream_t)stream, g);
+    VT_CHECK_LAUNCH("vt_reduce_grouped");
+    return VT_OK;
+}
+
+
 static inline RowMap to_map(vtRowMap m) { return RowMap{m.grp, m.stride, m.off}; }
 
 extern "C" int vt_layernorm_fwd(const float* x, vtRowMap xmap, const float* gamma, const float* beta, float eps, int64_t rows,
@@ -361,15 +403,13 @@ extern "C" int vt_layernorm_fwd(const float* x, vtRowMap xmap, const float* gamm
 #define VT_LN_BWD_GRID 512
 extern "C" size_t vt_layernorm_bwd_workspace_bytes(int32_t dim) { return (size_t)VT_LN_BWD_GRID * 3 * dim * sizeof(float); }
 
-extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xmap, const float* gamma, const float* mean,
-                                const float* rstd, const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16,
-                                float* dgamma, float* dbeta, float* dxsum, void* workspace, vtStream stream) {
-    VT_CHECK_ARG(dy_bf16 && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "vt_layernorm_bwd: null pointer");
+int vt_layernorm_bwd_partials(const void* dy_bf16, const float* x, vtRowMap xmap, const float* gamma, const float* mean, const float* rstd,
+                              const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16, float* part, int* nslab, vtStream stream) {
+    VT_CHECK_ARG(dy_bf16 && x && gamma && mean && rstd && dx && part, "vt_layernorm_bwd: null pointer");
     VT_CHECK_ARG(rows > 0 && ((dim % 256 == 0 && dim >= 256 && dim <= 1024) || dim == 128 || dim == 384),
                  "vt_layernorm_bwd: dim=%d must be 128, 256, 384, 512, 768 or 1024", dim);
     const int grid = (int)((rows + 3) / 4 < VT_LN_BWD_GRID ? (rows + 3) / 4 : VT_LN_BWD_GRID);
     hipStream_t s = (hipStream_t)stream;
-    float* part = (float*)workspace;
 #define LN_BWD(V, VEC) hipLaunchKernelGGL((ln_bwd_kernel<V, VEC>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy_bf16, x, to_map(xmap), gamma, mean, rstd, dres, rows, dx, (bf16_t*)dx_bf16, part)
     switch (dim) {
         case 128: LN_BWD(1, 2); break;
@@ -381,9 +421,20 @@ extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xm
     }
 #undef LN_BWD
     VT_CHECK_LAUNCH("vt_layernorm_bwd");
+    *nslab = grid;
+    return VT_OK;
+}
+
+extern "C" int vt_layernorm_bwd(const void* dy_bf16, const float* x, vtRowMap xmap, const float* gamma, const float* mean,
+                                const float* rstd, const float* dres, int64_t rows, int32_t dim, float* dx, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* dxsum, void* workspace, vtStream stream) {
+    VT_CHECK_ARG(dgamma && dbeta && workspace, "vt_layernorm_bwd: null pointer");
+    int grid = 0;
+    int rc = vt_layernorm_bwd_partials(dy_bf16, x, xmap, gamma, mean, rstd, dres, rows, dim, dx, dx_bf16, (float*)workspace, &grid, stream);
+    if (rc) return rc;
     ReduceOuts ro;
     ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = dxsum;
-    launch_reduce_partials(part, grid, (int64_t)3 * dim, dim, dxsum ? 3 : 2, ro, s);
+    launch_reduce_partials((const float*)workspace, grid, (int64_t)3 * dim, dim, dxsum ? 3 : 2, ro, (hipStream_t)stream);
     VT_CHECK_LAUNCH("vt_layernorm_bwd/reduce");
     return VT_OK;
 }
