@@ -65,8 +65,6 @@ class LARPTokenizer(nn.Module):
         assert temporal_patch_size >= 1
         assert (temporal_patch_size, patch_size) == (decoder_temporal_patch_size, decoder_patch_size), \
             "unpatchify uses the ENCODER patch sizes (larp_tokenizer.py:447-449): encoder and decoder patch sizes must match"
-        if temporal_patch_size == 1 and not (learned_encoder_latent_query_embed or True):
-            pass
         assert encoder_hidden_size == decoder_hidden_size and encoder_num_heads == decoder_num_heads, \
             "the fused engine is built for equal encoder/decoder width"
 
