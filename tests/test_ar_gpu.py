@@ -384,3 +384,12 @@ def test_tokenizer_indices_feed_the_prior():
     loss.backward()
     assert logits.shape == (4, n, cfg["codebook_size"]) and torch.isfinite(loss)
     assert abs(loss.item() - math.log(cfg["codebook_size"])) < 0.5
+
+
+def test_bench_ar_leg_runs():
+    """the `bench.py --ar SIZE` leg (training step + KV-cache generation of the prior) on a short sequence"""
+    import bench
+    import video_tokenizer_amd as vt
+    r = bench.ar_prior_step(vt, "S", steps=2, warmup=1, batch=2, seq=128, gen_batch=2, vocab=512)
+    assert r["model"] == "llama-abs-S" and r["train"]["tokens_per_s"] > 0 and np.isfinite(r["train"]["loss"])
+    assert r["generate_cfg1"]["new_tokens"] == 128 and r["generate_cfg2"]["tokens_per_s"] > 0

@@ -105,3 +105,15 @@ def test_sq_tokenizer_forward_backward_matches_oracle():
     bad = [(n, rel(q.grad.cpu(), p[n].grad)) for n, q in model.named_parameters() if q.requires_grad and rel(q.grad.cpu(), p[n].grad) > 6e-2]
     assert not bad, bad
     assert model.bottleneck.embedding.weight.grad is None
+
+
+def test_bench_sq_leg_runs():
+    """the `bench.py --sq` leg: the step with the bottleneck the shipped yaml carries (cfgs/larp_tokenizer.yaml:73), here at the tiny geometry"""
+    import bench
+    import video_tokenizer_amd as vt
+    cfg = vt.config.geometry("A")
+    spec = vt.config.model_spec(cfg, stochastic=True)
+    spec["args"]["encoder_depth"] = spec["args"]["decoder_depth"] = 2
+    x = torch.from_numpy(vt.config.synthetic_clips(2, cfg["frame_num"], cfg["input_size"], 5)).cuda()
+    r = bench.sq_step(vt, cfg, spec, x, steps=2, warmup=1)
+    assert r["bottleneck_type"] == "sq" and r["clips_per_s"] > 0 and np.isfinite(r["loss"]) and r["distinct_codes_in_batch"] >= 1
