@@ -90,8 +90,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const int64_t pr = xmap(row);
         const float mu = mean[row], rs = rstd[row];
-        F xh[V], a[V];
+        F xh[V], a[V], rv[V];
         float s1 = 0.f, s2 = 0.f;
+        if (dres) {   // issued with the row's other loads: one more 3 KB per wave in flight while the two row sums are taken
+#pragma unroll
+            for (int i = 0; i < V; ++i) rv[i] = *(const F*)(dres + pr * DIM + (i * 64 + lane) * VEC);
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const F xv = *(const F*)(x + pr * DIM + (i * 64 + lane) * VEC);
@@ -115,9 +119,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < VEC; ++r) o[r] = rs * (a[i][r] - m1 - xh[i][r] * m2);
             if (dres) {
-                const F rv = *(const F*)(dres + pr * DIM + (i * 64 + lane) * VEC);
 #pragma unroll
-                for (int r = 0; r < VEC; ++r) o[r] += rv[r];
+                for (int r = 0; r < VEC; ++r) o[r] += rv[i][r];
             }
 #pragma unroll
             for (int r = 0; r < VEC; ++r) as[i][r] += o[r];
