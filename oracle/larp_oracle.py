@@ -154,8 +154,19 @@ def encoder_parallel(context, query, p, prefix, depth, num_heads, emu=False):
 # --------------------------------------------------------------------------------------
 
 
+def entropy_loss(affinity, temperature=0.01):
+    """bottleneck.py:12-33 (loss_type 'softmax')"""
+    flat = affinity.reshape(-1, affinity.shape[-1]) / temperature
+    probs = F.softmax(flat, dim=-1)
+    log_probs = F.log_softmax(flat + 1e-5, dim=-1)
+    avg_probs = probs.mean(dim=0)
+    avg_entropy = -torch.sum(avg_probs * torch.log(avg_probs + 1e-5))
+    sample_entropy = -torch.mean(torch.sum(probs * log_probs, dim=-1))
+    return sample_entropy - avg_entropy, sample_entropy, avg_entropy
+
+
 def vq_forward(z, emb_weight, mode="L", l2_normalized=True, beta=0.25, codebook_w=1.0,
-               temperature=0.03, generator=None, force_idx=None):
+               temperature=0.03, generator=None, force_idx=None, entropy_w=0.0, entropy_temperature=0.01):
     """bottleneck.py:262-324 in fp32.  mode 'L': stochastic=False argmin of the 3-term
     distance (:282-290); 'D': eval-deterministic argmax(softmax(cos/tau)) (:275-278);
     'S': multinomial sample (:280).  Returns the same dict keys."""
@@ -183,13 +194,17 @@ def vq_forward(z, emb_weight, mode="L", l2_normalized=True, beta=0.25, codebook_
     loss_commit = ((quantized.detach() - z) ** 2).mean()
     loss_codebook = ((quantized - z.detach()) ** 2).mean()
     zero = torch.tensor(0.0)
-    loss = beta * loss_commit + codebook_w * loss_codebook + 0.0 * zero
+    le = se = ae = zero
+    if entropy_w > 0:                                       # :298-303 (only defined on the stochastic=False branch, which computes `d`)
+        assert mode == "L"
+        le, se, ae = entropy_loss(-dist, entropy_temperature)
+    loss = beta * loss_commit + codebook_w * loss_codebook + entropy_w * le
     quantized_st = z + (quantized - z).detach()
     return {
         "unregularized_z": z, "emb": emb, "regularized_z": quantized_st,
         "bottleneck_rep": idx.reshape(z.shape[0], z.shape[1]),
         "loss_q": loss, "loss_commit": loss_commit, "loss_codebook": loss_codebook,
-        "loss_entropy": zero, "per_sample_entropy": zero, "codebook_entropy": zero,
+        "loss_entropy": le, "per_sample_entropy": se, "codebook_entropy": ae,
     }
 
 

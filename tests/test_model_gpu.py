@@ -633,7 +633,7 @@ def _extra_state(model, sd, seed):
     return out
 
 
-@pytest.mark.parametrize("variant", ["learned_embeddings", "fixed_queries_per_frame_patches", "normalised_bottleneck"])
+@pytest.mark.parametrize("variant", ["learned_embeddings", "fixed_queries_per_frame_patches", "normalised_bottleneck", "entropy_loss"])
 def test_constructor_options_on_the_composed_path_match_oracle(variant):
     """Options of models/larp_tokenizer.py:106-180 that the fused engine does not carry run on the composed path (same kernels through the
     sub-modules' autograd functions): learned factorised PEs + all four token-type embeddings + learned decoder latent PE; fixed (buffer)
@@ -652,6 +652,10 @@ def test_constructor_options_on_the_composed_path_match_oracle(variant):
     spec["args"].update(over)
     if variant == "normalised_bottleneck":
         spec["args"]["bottleneck"]["args"]["norm"] = "ln_d"
+    vq_kw = {}
+    if variant == "entropy_loss":      # bottleneck.py:12-33, 298-303 (torch ops in this build, see SimpleVectorQuantizer._entropy_loss); T = 0.5 keeps the softmax soft
+        spec["args"]["bottleneck"]["args"]["regularizer"]["args"].update(entropy_loss_weight=0.1, entropy_loss_temperature=0.5)
+        vq_kw = dict(entropy_w=0.1, entropy_temperature=0.5)
     model = vt.make(spec)
     assert model._composed and model._engine is None
     sd = _extra_state(model, O.init_state_dict(cfg, seed=7, query_std=1.0), 900)
@@ -664,11 +668,14 @@ def test_constructor_options_on_the_composed_path_match_oracle(variant):
     torch.cuda.synchronize()
     idx = out["bottleneck_rep"].reshape(-1).cpu()
     p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
-    free = O.tokenizer_forward(p, cfg, x, "L", emu=True)
+    free = O.tokenizer_forward(p, cfg, x, "L", emu=True, **vq_kw)
     agree = (free["bottleneck_rep"].reshape(-1) == idx).float().mean().item()
     assert agree > 0.95, agree
     assert torch.unique(idx).numel() >= 0.25 * idx.numel()
-    ref = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_idx=idx)
+    ref = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_idx=idx, **vq_kw)
+    if variant == "entropy_loss":
+        assert abs(out["loss_entropy"].item() - ref["loss_entropy"].item()) < 2e-3 and abs(ref["loss_entropy"].item()) > 1e-3
+        assert abs(out["codebook_entropy"].item() - ref["codebook_entropy"].item()) < 2e-3
     ((ref["pred_frames"] * w).sum() + 0.7 * ref["loss_q"]).backward()
     assert rel(out["pred_frames"].detach().cpu(), ref["pred_frames"].detach()) < 2e-2
     assert abs(out["loss_q"].item() - ref["loss_q"].item()) < 2e-3 * max(1.0, abs(ref["loss_q"].item()))

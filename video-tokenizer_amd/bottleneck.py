@@ -24,8 +24,9 @@ class SimpleVectorQuantizer(nn.Module):
         self.beta = commitment_loss_weight
         self.codebook_loss_weight = codebook_loss_weight
         self.entropy_loss_weight = entropy_loss_weight
-        if entropy_loss_weight > 0:
-            raise NotImplementedError("entropy_loss_weight > 0 is not built (every shipped yaml sets 0.0)")
+        if entropy_loss_weight > 0 and stochastic:
+            # the reference computes the term from `d`, which only exists on the stochastic=False branch (bottleneck.py:282-303): NameError there
+            raise ValueError("entropy_loss_weight > 0 needs stochastic=False (the reference's entropy term reads the L2 distances of that branch)")
         assert isinstance(l2_normalized, bool)
         self.l2_normalized = l2_normalized
         self.stochastic = stochastic
@@ -69,8 +70,31 @@ class SimpleVectorQuantizer(nn.Module):
         if self.same_index_shape:
             idx = idx.reshape(rz.shape[0], rz.shape[1])
         zero = torch.zeros((), device=z.device, dtype=torch.float32)
+        le = se = ae = zero
+        if self.entropy_loss_weight > 0:
+            le, se, ae = self._entropy_loss(z.float())
+            lq = lq + self.entropy_loss_weight * le
         return {"unregularized_z": zn, "emb": emb, "regularized_z": rz, "bottleneck_rep": idx, "loss_q": lq, "loss_commit": lc,
-                "loss_codebook": lcb, "loss_entropy": zero, "per_sample_entropy": zero, "codebook_entropy": zero}
+                "loss_codebook": lcb, "loss_entropy": le, "per_sample_entropy": se, "codebook_entropy": ae}
+
+    def _entropy_loss(self, z):
+        """bottleneck.py:12-33, 298-303: entropy of softmax(-d / T) per token minus the entropy of its batch average.  NOT a kernel of this
+        build: no shipped yaml enables it (entropy_loss_weight 0.0), so the term is the reference's own unfused sequence of torch ops on the GPU
+        (one library GEMM for the N x K distances, softmax, two reductions: ~1 GB of traffic at N = K = 8192), differentiable through torch
+        autograd into z and the codebook next to the fused quantizer's gradients.  A tokenizer that enables it runs on the composed path."""
+        import torch.nn.functional as F
+        zf = z.reshape(-1, z.shape[-1])
+        emb = self.embedding.weight
+        if self.l2_normalized:
+            zf, emb = F.normalize(zf, p=2, dim=-1), F.normalize(emb, p=2, dim=-1)
+        d = zf.pow(2).sum(1, keepdim=True) + emb.pow(2).sum(1) - 2 * zf @ emb.t()
+        flat = -d / self.entropy_loss_temperature
+        probs = F.softmax(flat, dim=-1)
+        log_probs = F.log_softmax(flat + 1e-5, dim=-1)
+        avg_probs = probs.mean(dim=0)
+        avg_entropy = -torch.sum(avg_probs * torch.log(avg_probs + 1e-5))
+        sample_entropy = -torch.mean(torch.sum(probs * log_probs, dim=-1))
+        return sample_entropy - avg_entropy, sample_entropy, avg_entropy
 
     def get_codebook_entry(self, indices, shape=None):
         """bottleneck.py:327-341"""

@@ -61,6 +61,7 @@ class LARPTokenizer(nn.Module):
                      fixed_latent_queries=not learned_encoder_latent_query_embed, per_frame_patch_embed=temporal_patch_size == 1)
         bn = bottleneck.get("args", {}).get("norm") if isinstance(bottleneck, dict) and bottleneck_type == "vq" else None
         extra["bottleneck_norm"] = bn is not None and str(bn).lower() not in ("no", "none")
+        extra["entropy_loss"] = bottleneck_type == "vq" and float(bottleneck["args"]["regularizer"]["args"].get("entropy_loss_weight", 0.0)) > 0
         self._composed = bottleneck_type == "fsq" or any(extra.values())
         assert temporal_patch_size >= 1
         assert (temporal_patch_size, patch_size) == (decoder_temporal_patch_size, decoder_patch_size), \
