@@ -337,21 +337,31 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 }
                 continue;
             }
-            constexpr int UNR = 2;
-#pragma unroll UNR
-            for (int it = 0; it < TM * UPR / G::THREADS; ++it) {
-                const int slot = it * G::THREADS + tid;
-                const int row = slot / UPR, c = slot - row * UPR;
-                const int m = em0 + row, n = en0 + c * 4;
-                if (m >= p.M || n >= p.N) continue;
-                const bf16x4 h = *(const bf16x4*)(smem + row * STRIDE + c * 8);
-                bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
-                if constexpr (EPI == VT_EPI_BF16) {
+            // read-back in batches of RB image reads followed by their stores: with one read in flight per store (the compiler's order for
+            // the plain loop) every store waits a full LDS round trip
+            constexpr int NITS = TM * UPR / G::THREADS, RB = 3;
+            static_assert(NITS % RB == 0, "read-back batches");
+#pragma unroll 1
+            for (int it0 = 0; it0 < NITS; it0 += RB) {
+                bf16x4 hh[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int slot = (it0 + u) * G::THREADS + tid;
+                    const int row = slot / UPR, c = slot - row * UPR;
+                    hh[u] = *(const bf16x4*)(smem + row * STRIDE + c * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int slot = (it0 + u) * G::THREADS + tid;
+                    const int row = slot / UPR, c = slot - row * UPR;
+                    const int m = em0 + row, n = en0 + c * 4;
+                    if (m >= p.M || n >= p.N) continue;
+                    const bf16x4 h = hh[u];
+                    bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
                     st_stream((bf16x4*)o, h);
-                } else {
-                    st_stream((bf16x4*)o, h);
-                    st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n),
-                              (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))});
+                    if constexpr (EPI == VT_EPI_BF16_GELU)
+                        st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n),
+                                  (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))});
                 }
             }
             continue;
