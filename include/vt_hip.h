@@ -83,8 +83,9 @@ typedef struct {
     int32_t tile;                            /* tile generation for THIS call: 0 = automatic (use this; 192x192x64 tiles on a
                                                 3-stage LDS-DMA ring, one persistent workgroup per CU, when the problem fills
                                                 them, else 128x128x64).  Tests / tuning: 1 = force 128, 2 = force 192, 5 = 192x96
-                                                two workgroups per CU, 6 = 192x192 one tile per workgroup, 3/4 = timing
-                                                ablations with WRONG results.  Results do not depend on the choice (same fp32
+                                                two workgroups per CU, 6 = 192x192 one tile per workgroup, 7 = the M <= 64
+                                                weight-streaming kernel, 8..15 = 192x192 with every other CU starting 1..8 us late
+                                                (timing experiment, correct results), 3/4 = timing ablations with WRONG results.  Results do not depend on the choice (same fp32
                                                 summation order).  The library keeps no such setting between calls */
 } vtGemmNT;
 

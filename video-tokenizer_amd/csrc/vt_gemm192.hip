@@ -195,6 +195,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 
     set_tile(blockIdx.x);
     issue_tile(0);
+    if (a.dbg >= 8 && ((blockIdx.x >> 3) & 1))          // timing experiment (vtGemmNT.tile 8..15): every other CU of an XCD starts 1..8 us late
+        for (int i = 0; i < a.dbg - 7; ++i) __builtin_amdgcn_s_sleep(32);
     constexpr bool PERSIST = WN == 4;   // the 192x96 experiment stays one tile per workgroup
     for (int it = blockIdx.x; it < nwg; it = PERSIST ? it + (int)gridDim.x : nwg) {
     // K-tile 0 of this output tile is already in flight (issued above, or before the previous tile's epilogue)
