@@ -384,6 +384,13 @@ def test_tokenizer_indices_feed_the_prior():
     loss.backward()
     assert logits.shape == (4, n, cfg["codebook_size"]) and torch.isfinite(loss)
     assert abs(loss.item() - math.log(cfg["codebook_size"])) < 0.5
+    # and back (sample.py:168-190): sampled token ids -> decode_from_bottleneck -> video
+    ar.eval()
+    ids = ar.sample(torch.tensor([0, 2], device="cuda"), cfg_scale=1.5, temperature=1.0, top_k=100, top_p=0.95)
+    ar.reset_caches()
+    assert ids.shape == (2, n) and int(ids.max()) < cfg["codebook_size"]
+    video = tokz.decode_from_bottleneck(ids.long())
+    assert video.shape == (2, 3, cfg["frame_num"], cfg["input_size"], cfg["input_size"]) and bool(torch.isfinite(video).all())
 
 
 def test_bench_ar_leg_runs():
