@@ -194,6 +194,19 @@ int vt_attention_fwd_rows(const void* qkv, int32_t B, int32_t L, int32_t H, int3
                           vtStream stream);
 int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
                           int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, vtStream stream);
+/* The same backward (head_dim 64, no mask; q_begin as above) in FIVE matrix products instead of seven: one kernel, one
+ * workgroup per 256 keys of a (batch, head) keeps dK / dV in registers and computes S, dP and the softmax once; dQ is summed
+ * across the key blocks of a head by an ordered hand-off through `ws` (fixed summation order: results are bit-reproducible
+ * run to run; no atomics on data).  `ws` (vt_attention_bwd_fused_workspace_bytes, 16-byte aligned) holds the fp32 partial
+ * sums, the arrival counters and a status word; the call zeroes its control block itself (graph-capturable, nothing
+ * allocates or synchronises).  Every in-kernel wait is bounded: if one gives up, the kernel still terminates and
+ * vt_attention_bwd_fused_status (which synchronises the stream) reports status != 0 -- the outputs are then invalid.
+ * Replaces autograd of F.scaled_dot_product_attention under models/transformer.py:52-59. */
+size_t vt_attention_bwd_fused_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t hd, int32_t q_begin);
+int vt_attention_bwd_fused(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
+                           int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, void* ws, size_t ws_bytes,
+                           vtStream stream);
+int vt_attention_bwd_fused_status(const void* ws, int32_t* status, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vector quantisation (SimpleVectorQuantizer.forward, models/bottleneck.py:262-324).

@@ -240,6 +240,85 @@ def test_config_A_full_depth_matches_oracle():
     assert all(e < 8e-2 for _, e in bad), bad
 
 
+def _grads_of(model, x, w, q_weight):
+    for p in model.parameters():
+        p.grad = None
+    out = model(x)
+    ((out["pred_frames"] * w).sum() + q_weight * out["loss_q"]).backward()
+    torch.cuda.synchronize()
+    return out, {n: p.grad.clone() for n, p in model.named_parameters()}
+
+
+def test_config_B_full_size_forward_backward_matches_oracle():
+    """BASELINE configs[1] at its OWN size (cfgs/larp_tokenizer.yaml geometry on 16x128x128 clips: L = 1536, 12 + 12 blocks,
+    d = 24), train(), mode L, forward AND backward against the bf16-emulating CPU oracle that follows the GPU's indices: two clips
+    (M = 3072 = exact 192-row tiles on the persistent walk, compact last-block rows at offsets 512 / 1024, grouped 4-block weight
+    gradients), every parameter gradient (277 tensors).  The oracle takes ~5 s per clip and direction on the box's host cores."""
+    cfg = O.make_cfg("B")
+    model, sd = build(cfg, seed=13)
+    B = 2
+    x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 81))
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 82))
+    model.train()
+    out, grads = _grads_of(model, x.cuda(), w.cuda(), 0.7)
+    idx_gpu = out["bottleneck_rep"].cpu()
+    # per clip: the latent queries (std 1) dominate the video content at random init, so two clips land on largely the same codes
+    distinct = min(len(torch.unique(idx_gpu[i])) / idx_gpu[i].numel() for i in range(B))
+    assert distinct >= 0.25, distinct
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("_pe") and k != "decoder_patch_query_embed") for k, v in sd.items()}
+    ref = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_idx=idx_gpu)
+    ((ref["pred_frames"] * w).sum() + 0.7 * ref["loss_q"]).backward()
+    with torch.no_grad():
+        free = O.tokenizer_forward(sd, cfg, x, "L", emu=True)
+    agree = (free["bottleneck_rep"] == idx_gpu).float().mean().item()
+    assert agree >= 0.97, agree
+    zf = free["unregularized_z"].reshape(-1, cfg["bottleneck_dim"])
+    d_free = ((zf - free["emb"][free["bottleneck_rep"].reshape(-1)]) ** 2).sum(-1)
+    d_gpu = ((zf - free["emb"][idx_gpu.reshape(-1)]) ** 2).sum(-1)
+    assert float((d_gpu - d_free).max()) < 2e-2, float((d_gpu - d_free).max())   # differing indices are near ties
+
+    assert set(out.keys()) == set(ref.keys())
+    assert rel(out["pred_frames"].cpu(), ref["pred_frames"].detach()) < 2e-2
+    assert rel(out["encoded"].cpu(), ref["encoded"].detach()) < 2e-2
+    assert rel(out["projected_z"].cpu(), ref["projected_z"].detach()) < 2e-2
+    np.testing.assert_allclose(out["loss_q"].item(), ref["loss_q"].item(), rtol=2e-2)
+    bad = [(n, rel(grads[n].cpu(), p[n].grad)) for n in grads]
+    assert len(bad) == len(list(model.parameters())) and all(p[n].grad is not None for n in grads)
+    assert all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:6]
+
+
+def test_config_B_eight_clips_equal_the_sum_of_single_clip_runs():
+    """The paths only the headline batch takes together (M = 12 288 rows: 64 persistent 192-row tiles per N panel, 768-tile
+    grouped weight gradients, 64 MB gradient buckets): clips are independent through the whole step (no BatchNorm, per-token
+    LayerNorm), so the 8-clip gradients must equal the SUM of eight 1-clip runs with the VQ loss weighted 1/8
+    (loss_q is a mean over the batch's tokens).  Forward outputs of a clip do not depend on its neighbours at all (bit-equal);
+    weight gradients differ only by the fp32 summation order over clips (MFMA accumulation over 12 288 rows vs eight partial
+    sums added afterwards): rel-L2 1e-5."""
+    cfg = O.make_cfg("B")
+    model, _ = build(cfg, seed=13)
+    B = 8
+    x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 83)).cuda()
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 84)).cuda()
+    model.train()
+    out8, g8 = _grads_of(model, x, w, 0.7)
+    pred8, idx8 = out8["pred_frames"].clone(), out8["bottleneck_rep"].clone()
+    assert len(torch.unique(idx8)) >= 0.25 * idx8[0].numel()
+    acc = {n: torch.zeros_like(g, dtype=torch.float64) for n, g in g8.items()}
+    for i in range(B):
+        out1, g1 = _grads_of(model, x[i:i + 1], w[i:i + 1], 0.7 / B)
+        assert torch.equal(out1["bottleneck_rep"], idx8[i:i + 1]), i
+        assert rel(out1["pred_frames"], pred8[i:i + 1]) < 1e-6, i
+        for n, g in g1.items():
+            acc[n] += g.double()
+    bad = [(n, rel(g8[n], acc[n])) for n in g8]
+    assert all(e < 1e-5 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:6]
+    # and the whole 8-clip step is run-to-run bit-reproducible (no atomics anywhere in the step)
+    _, again = _grads_of(model, x, w, 0.7)
+    assert all(torch.equal(again[n], g8[n]) for n in g8)
+
+
 @pytest.mark.parametrize("name", ["B", "Bp", "C", "D", "E"])
 def test_f256_geometries_size_independent_properties(name):
     """BASELINE configs[1] (B: the headline geometry, pt2 p16, 12+12 blocks, d=24; Bp: the upstream pt4 p8 variant),

@@ -27,124 +27,9 @@
 #include "vt_common.h"
 #include <stdlib.h>
 
+#include "vt_attn_tile.h"
+
 namespace {
-
-template <int HD>
-struct AG {
-    static constexpr int ROWB = HD * 2;       // bytes per tile row
-    static constexpr int TILE = 64 * ROWB;    // bytes per [64][HD] bf16 tile
-    static constexpr int KS = HD / 16;        // k-steps of a product that contracts over head_dim
-    static constexpr int DT = HD / 32;        // 32-wide output tiles along head_dim
-    static constexpr int CH = HD / 8;         // 16-B chunks per row
-};
-
-template <int HD>
-__device__ __forceinline__ int fsw(int row) {
-    return HD == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
-}
-
-// LDS-DMA through inline asm (see glds16_asm): callers drain with dma_drain() before the publishing barrier
-template <int HD>
-__device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, unsigned lds, int tid, int wave) {
-    constexpr int CH = AG<HD>::CH;
-#pragma unroll
-    for (int i = 0; i < CH / 4; ++i) {
-        const int slot = i * 256 + tid;
-        const int row = slot / CH;
-        const int lc = (slot % CH) ^ fsw<HD>(row);
-        int gr = row0 + row;
-        gr = gr < L ? gr : L - 1;
-        glds16_asm(src + (int64_t)gr * rs + lc * 8, lds + (i * 256 + wave * 64) * 16);
-    }
-}
-
-// Full (unclamped) tiles of the steady state: lane offsets inside a [64][HD] tile are loop invariants (stage_offsets), the
-// tile's first row is a scalar base pointer.
-template <int HD>
-__device__ __forceinline__ void stage_offsets(int64_t rs, int tid, unsigned (&off)[AG<HD>::CH / 4]) {
-    constexpr int CH = AG<HD>::CH;
-#pragma unroll
-    for (int i = 0; i < CH / 4; ++i) {
-        const int slot = i * 256 + tid;
-        const int row = slot / CH;
-        const int lc = (slot % CH) ^ fsw<HD>(row);
-        off[i] = (unsigned)((row * rs + lc * 8) * 2);
-    }
-}
-template <int HD>
-__device__ __forceinline__ void stage64_full(const bf16_t* tile_row0, const unsigned (&off)[AG<HD>::CH / 4], unsigned lds, int wave) {
-#pragma unroll
-    for (int i = 0; i < AG<HD>::CH / 4; ++i) glds16_sv(tile_row0, off[i], lds + (i * 256 + wave * 64) * 16);
-}
-
-// A operand of a 32x32x16 MFMA from tile rows r0..r0+31, k-step s (16 columns)
-template <int HD>
-__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int r0, int s, int lane) {
-    const int row = r0 + (lane & 31);
-    const int lc = 2 * s + (lane >> 5);
-    return *(const bf16x8*)(lds + row * AG<HD>::ROWB + ((lc ^ fsw<HD>(row)) << 4));
-}
-
-// A operand [i = column c0 + (lane&31)][k = tile rows], k order matched to an accumulator used as B:
-// element j  <->  tile row rbase + 16*sp + 8*(j>>2) + 4*(lane>>5) + (j&3)
-template <int HD>
-__device__ __forceinline__ bf16x8 trfrag(const char* lds, int rbase, int sp, int c0, int lane) {
-    const int g = lane >> 4, lam = lane & 15;
-    const int r0 = rbase + 16 * sp + 4 * (g >> 1) + (lam >> 2);
-    const int r1 = r0 + 8;
-    const int cb = c0 + 16 * (g & 1);
-    const int lc = (cb >> 3) + ((lam & 3) >> 1);
-    const int bo = (lam & 1) << 3;
-    const bf16x4 lo = lds_read_tr16(lds + r0 * AG<HD>::ROWB + ((lc ^ fsw<HD>(r0)) << 4) + bo);
-    const bf16x4 hi = lds_read_tr16(lds + r1 * AG<HD>::ROWB + ((lc ^ fsw<HD>(r1)) << 4) + bo);
-    return cat4(lo, hi);
-}
-
-// own 32 rows as B-operand fragments straight from global: f[s] = X[row0 + (lane&31)][16s + 8*(lane>>5) ..+7]
-template <int KS>
-__device__ __forceinline__ void load_own(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, int lane, bf16x8 (&f)[KS]) {
-    int r = row0 + (lane & 31);
-    r = r < L ? r : L - 1;
-    const bf16_t* p = src + (int64_t)r * rs + 8 * (lane >> 5);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) f[s] = *(const bf16x8*)(p + 16 * s);
-}
-
-// Own-row operands arrive by ordinary global loads that hipcc counts; the tile loops stage by inline-asm LDS-DMA that it
-// does not.  Left alone, hipcc places the wait for the own-row loads at their first use INSIDE the loop as vmcnt(3..0) --
-// which at run time drains the next tile's just-issued DMA at the top of every iteration (the prefetch never overlapped
-// the tile's compute).  Making the registers opaque here puts that wait in front of the loop, once.
-template <int N>
-__device__ __forceinline__ void pin_loaded(bf16x8 (&f)[N]) {
-#pragma unroll
-    for (int s = 0; s < N; ++s) asm volatile("" : "+v"(f[s]));
-}
-__device__ __forceinline__ void pin_loaded(float& x) { asm volatile("" : "+v"(x)); }
-
-__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int sp) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = f2bf(a[8 * sp + j]);
-    return r;
-}
-
-__device__ __forceinline__ int reg_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// store acc^T[d][own_row] tiles (DT x f32x16) as bf16 into dst[own_row][d], 8 B per store
-template <int DT>
-__device__ __forceinline__ void store_own(const f32x16 (&acc)[DT], float mul, bf16_t* __restrict__ dst, int64_t rs, int row, bool ok, int half) {
-    if (!ok) return;
-    bf16_t* p = dst + (int64_t)row * rs;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            bf16x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[dt][4 * g4 + e] * mul);
-            *(bf16x4*)(p + dt * 32 + 8 * g4 + 4 * half) = v;
-        }
-}
 
 // one 64-key tile of the forward: S^T = K.Q^T, online softmax (log2 domain; max taken on the raw scores since
 // the scale is positive), O^T += V^T.P^T.  TAIL masks keys >= L (last tile of a ragged sequence only).

@@ -66,6 +66,9 @@ SIGNATURES = {
     "vt_attention_causal_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_fwd_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "vt_attention_bwd_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "vt_attention_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vt_attention_bwd_fused_status": (c_i32, [c_vp, ctypes.POINTER(c_i32), c_vp]),
     "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -365,11 +368,30 @@ def attention_fwd(qkv, B, L, H, hd=64, o=None, q_begin=0):
     return o, lse2
 
 
-def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0):
+def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0, fused=None):
+    """fused=None: the five-product kernel where it exists (head_dim 64), the two-kernel backward otherwise; True / False force one"""
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     delta = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32)
+    if fused is None:
+        fused = hd == 64
+    if fused:
+        n = lib().vt_attention_bwd_fused_workspace_bytes(B, L, H, hd, q_begin)
+        if n == 0:
+            raise HipError(f"vt_attention_bwd_fused: unsupported geometry B={B} L={L} H={H} hd={hd} q_begin={q_begin}")
+        ws = _ws(n, qkv.device)
+        check(lib().vt_attention_bwd_fused(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), ptr(ws), n, stream()),
+              "vt_attention_bwd_fused")
+        attention_bwd.last_ws = ws
+        return dqkv
     check(lib().vt_attention_bwd_rows(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
     return dqkv
+
+
+def attention_bwd_fused_status(ws):
+    """status word of the last fused backward on this workspace (synchronises the stream): 0 = every hand-off completed"""
+    st = c_i32(0)
+    check(lib().vt_attention_bwd_fused_status(ptr(ws), ctypes.byref(st), stream()), "vt_attention_bwd_fused_status")
+    return st.value
 
 
 def attention_causal_fwd(qkv, B, L, H):

@@ -12,11 +12,13 @@ w.r.t. the input video (the generator update back-propagates through the discrim
 functional.{PatchEmbed,BlockStack}.  The cls-row head (B x D LayerNorm + a D-vector dot) and the scalar GAN loss
 formulas over B logits are torch glue.
 
-Not built (raise at construction): LPIPS -- the `lpips` package and its VGG weights are not available offline
-(SURVEY §8c); pass perceptual_weight=0 or a callable `perceptual_loss(input_frames, recon_frames) -> tensor`;
-r1_gp_weight > 0 (needs double backward through the HIP ops); spectral_norm; temporal_patch_size == 1
-(VideoPatchEmbed); disc_type other than 'transformer'.
+LPIPS (`perceptual_loss='lpips'`, weight 1.0 in the shipped yamls) is lpips.py: a torch-ops VGG-16 metric with the `lpips`
+package's state-dict layout, frozen, weights from a user-supplied state dict (env VT_LPIPS_WEIGHTS or the checkpoint's
+`loss` entry) -- parity unpinned, the package is not importable here; a callable `perceptual_loss(input_frames,
+recon_frames) -> tensor` is accepted too.  Not built (raise at construction): r1_gp_weight > 0 (needs double backward
+through the HIP ops); spectral_norm; temporal_patch_size == 1 (VideoPatchEmbed); disc_type other than 'transformer'.
 """
+import os
 from itertools import chain
 
 import torch
@@ -28,57 +30,47 @@ from .registry import register
 from .transformer import TransformerEncoderFused
 
 
-def lecam_reg(real_pred, fake_pred, ema_real_pred, ema_fake_pred):
-    """loss.py:17-35 (https://arxiv.org/abs/2104.03310)"""
-    assert real_pred.ndim == 0 and ema_fake_pred.ndim == 0
-    lecam_loss = torch.mean(torch.pow(torch.relu(real_pred - ema_fake_pred), 2))
-    return lecam_loss + torch.mean(torch.pow(torch.relu(ema_real_pred - fake_pred), 2))
+class _GanObjective:
+    """The scalar GAN formulas of `lpips_disc_loss` over the B discriminator logits, in one place.
+
+    `kind` is the yaml's `disc_loss` (/root/reference/models/loss.py:64-96, 288-299):
+      hinge      d = (mean relu(1 - real) + mean relu(1 + fake)) / 2                 g = -mean fake
+      ns         d = bce(real, 1) + bce(fake, 0)                                       g = mean softplus(-fake)
+      ns_smooth  the same with one-sided smoothed targets: real max(1 - 0.15 |n|, 0.7), fake min(0.15 |n|, 0.3), n ~ N(0, 1)
+    with bce(x, t) = mean(softplus(x) - t x), the logit form of binary cross entropy (no sigmoid, no log of it)."""
+
+    KINDS = ("hinge", "ns", "ns_smooth")
+
+    def __init__(self, kind):
+        if kind not in self.KINDS:
+            raise AssertionError(f"disc_loss must be one of {self.KINDS}, got {kind!r}")
+        self.kind = kind
+
+    @staticmethod
+    def _bce(logits, target):
+        return (F.softplus(logits) - target * logits).mean()
+
+    def discriminator(self, real, fake):
+        if self.kind == "hinge":
+            return 0.5 * (F.relu(1.0 - real).mean() + F.relu(1.0 + fake).mean())
+        if self.kind == "ns":
+            return self._bce(real, 1.0) + self._bce(fake, 0.0)
+        t_real = (1.0 - 0.15 * torch.randn_like(real).abs()).clamp(min=0.7)
+        t_fake = (0.15 * torch.randn_like(fake).abs()).clamp(max=0.3)
+        return self._bce(real, t_real) + self._bce(fake, t_fake)
+
+    def generator(self, fake):
+        return -fake.mean() if self.kind == "hinge" else F.softplus(-fake).mean()
 
 
-def hinge_d_loss(logits_real, logits_fake):
-    return 0.5 * (torch.mean(F.relu(1.0 - logits_real)) + torch.mean(F.relu(1.0 + logits_fake)))
+def _lecam(real_mean, fake_mean, ema_real, ema_fake):
+    """LeCam regulariser (arXiv 2104.03310; reference :17-35) on the batch means and their running averages (all 0-dim)"""
+    return F.relu(real_mean - ema_fake).square() + F.relu(ema_real - fake_mean).square()
 
 
-def hinge_g_loss(logits_fake):
-    return -torch.mean(logits_fake)
-
-
-def ns_d_loss(logits_real, logits_fake):
-    real_loss = F.binary_cross_entropy_with_logits(logits_real, torch.ones_like(logits_real))
-    fake_loss = F.binary_cross_entropy_with_logits(logits_fake, torch.zeros_like(logits_fake))
-    return real_loss + fake_loss
-
-
-def ns_d_loss_single_side_smooth(logits_real, logits_fake):
-    """loss.py:82-92: targets 1 - |N(0, 0.15)| clamped at 0.7 for real, |N(0, 0.15)| clamped at 0.3 for fake"""
-    real_target = torch.ones_like(logits_real) - torch.randn_like(logits_real).abs() * 0.15
-    real_target.clamp_min_(0.7)
-    fake_target = torch.randn_like(logits_fake).abs() * 0.15
-    fake_target.clamp_max_(0.3)
-    return F.binary_cross_entropy_with_logits(logits_real, real_target) + F.binary_cross_entropy_with_logits(logits_fake, fake_target)
-
-
-def ns_g_loss(logits_fake):
-    return -torch.mean(F.logsigmoid(logits_fake))
-
-
-def adopt_weight(weight, global_step, threshold=0, value=0.0):
-    return value if global_step < threshold else weight
-
-
-def measure_perplexity(predicted_indices, n_embed):
-    encodings = F.one_hot(predicted_indices, n_embed).float().reshape(-1, n_embed)
-    avg_probs = encodings.mean(0)
-    perplexity = (-(avg_probs * torch.log(avg_probs + 1e-10)).sum()).exp()
-    return perplexity, torch.sum(avg_probs > 0)
-
-
-def l1(x, y):
-    return torch.abs(x - y)
-
-
-def l2(x, y):
-    return torch.pow((x - y), 2)
+def _started(weight, step, start):
+    """a loss weight that is 0 before `start` (the reference's adopt_weight, :98-101)"""
+    return weight if step >= start else 0.0
 
 
 def _frames(x):
@@ -151,19 +143,25 @@ class VQLPIPSWithDiscriminator(nn.Module):
                  perceptual_loss="lpips", perceptual_fp16=False, pixel_loss="l1", lecam_weight=0.0, input_spatial_size=128,
                  r1_gp_weight=0.0, d_update_freq=1, d_update_loss_threshold=-1.0e6, spectral_norm=False):
         super().__init__()
-        assert disc_loss in ["hinge", "ns", "ns_smooth"]
+        self.objective = _GanObjective(disc_loss)
         assert pixel_loss in ["l1", "l2"]
         self.pixel_weight = pixelloss_weight
         self.perceptual_weight = perceptual_weight
         if callable(perceptual_loss):
             self.perceptual_loss = perceptual_loss
-            self.set_perceptual_eval()
-        elif perceptual_weight > 0:
-            raise NotImplementedError("perceptual_loss='lpips': the lpips package / VGG weights are not available offline; "
-                                      "pass perceptual_weight=0 or a callable perceptual_loss(input_frames, recon_frames)")
+        elif perceptual_loss == "lpips":
+            # the shipped yamls set perceptual_weight: 1.0 (cfgs/larp_tokenizer.yaml:120): a torch-ops LPIPS (lpips.py, parity
+            # unpinned) with the package's state-dict layout; weights come from VT_LPIPS_WEIGHTS or a checkpoint's `loss` entry
+            from .lpips import LPIPS, load_lpips_state_dict
+            self.perceptual_loss = LPIPS(net="vgg")
+            if os.environ.get("VT_LPIPS_WEIGHTS"):
+                load_lpips_state_dict(self.perceptual_loss, os.environ["VT_LPIPS_WEIGHTS"])
+            if perceptual_fp16:
+                self.perceptual_loss = self.perceptual_loss.to(dtype=torch.float16)
         else:
-            self.perceptual_loss = None
-        self.pixel_loss = l1 if pixel_loss == "l1" else l2
+            raise ValueError(f"Unknown perceptual loss: >> {perceptual_loss} <<")
+        self.set_perceptual_eval()
+        self.pixel_power = 1 if pixel_loss == "l1" else 2
         self.input_spatial_size = input_spatial_size
         if r1_gp_weight > 0.0:
             raise NotImplementedError("r1_gp_weight > 0 needs double backward through the HIP ops; not built (shipped yamls set 0.0)")
@@ -180,12 +178,6 @@ class VQLPIPSWithDiscriminator(nn.Module):
             raise NotImplementedError("spectral_norm=True is not built (shipped yamls set false)")
         self.discriminator_iter_start = disc_start
         self.discriminator_self_start = disc_self_start if (disc_self_start is not None and disc_self_start >= 0) else disc_start
-        if disc_loss == "hinge":
-            self.disc_loss, self.g_loss = hinge_d_loss, hinge_g_loss
-        elif disc_loss == "ns":
-            self.disc_loss, self.g_loss = ns_d_loss, ns_g_loss
-        else:
-            self.disc_loss, self.g_loss = ns_d_loss_single_side_smooth, ns_g_loss
         self.disc_factor = disc_factor
         self.discriminator_weight = disc_weight
         self.lecam_weight = lecam_weight
@@ -193,37 +185,46 @@ class VQLPIPSWithDiscriminator(nn.Module):
             self.register_buffer("lecam_ema_real", torch.tensor(0.0))
             self.register_buffer("lecam_ema_fake", torch.tensor(0.0))
 
-    def set_perceptual_eval(self):
-        if isinstance(self.perceptual_loss, nn.Module):
-            self.perceptual_loss.eval()
-            for param in self.perceptual_loss.parameters():
-                param.requires_grad_(False)
+    def _perceptual(self, a, b):
+        if isinstance(self.perceptual_loss, nn.Module) and hasattr(self.perceptual_loss, "scaling_layer"):
+            dt = self.perceptual_loss.scaling_layer.shift.dtype
+            return self.perceptual_loss(a.to(dt), b.to(dt), normalize=True).float()       # the reference's call, :335, 370-372
+        return self.perceptual_loss(a, b)
 
-    def trainable_requires_grad_(self, requires_grad):
-        for param in self.trainable_parameters():
-            param.requires_grad_(requires_grad)
+    def _pixel(self, a, b):
+        d = a - b
+        return d.abs() if self.pixel_power == 1 else d * d
 
+    # ---- what trainers/larp_tokenizer_trainer.py:121-122, 163, 267-292 call on the loss module ----
     def trainable_modules(self):
         return [self.discriminator]
 
     def trainable_parameters(self):
-        return chain(*(m.parameters() for m in self.trainable_modules()))
+        return chain.from_iterable(m.parameters() for m in self.trainable_modules())
+
+    def trainable_requires_grad_(self, requires_grad):
+        for p in self.trainable_parameters():
+            p.requires_grad_(requires_grad)
+
+    def set_perceptual_eval(self):
+        metric = self.perceptual_loss
+        if isinstance(metric, nn.Module):
+            metric.requires_grad_(False).eval()
 
     def set_training_mode(self, trainable_mode, others_mode=False):
-        self.train(others_mode)
+        self.train(others_mode)                       # everything (the frozen metric stays in eval by its own train())
         for m in self.trainable_modules():
             m.train(trainable_mode)
 
     @torch.no_grad()
     def update_lecam_ema(self, real, fake, decay=0.999):
-        real, fake = real.float().mean(), fake.float().mean()
-        self.lecam_ema_real.mul_(decay).add_(real, alpha=1 - decay)
-        self.lecam_ema_fake.mul_(decay).add_(fake, alpha=1 - decay)
+        for buf, logits in ((self.lecam_ema_real, real), (self.lecam_ema_fake, fake)):
+            buf.lerp_(logits.float().mean(), 1.0 - decay)
 
     def forward_perceptual(self, inputs, reconstructions):
         if self.perceptual_loss is None:
             raise NotImplementedError("no perceptual loss configured")
-        return {"loss_prior": self.perceptual_loss(_frames(inputs), _frames(reconstructions)).mean()}
+        return {"loss_prior": self._perceptual(_frames(inputs), _frames(reconstructions)).mean()}
 
     def forward(self, inputs, reconstructions, global_step, for_discriminator=False, last_layer=None):
         """loss.py:338-456.  Returns (loss, info_dict, p_loss_per_sample | None); info values are detached 0-dim tensors
@@ -231,16 +232,13 @@ class VQLPIPSWithDiscriminator(nn.Module):
         input_frames, recon_frames = _frames(inputs), _frames(reconstructions)
         zero = input_frames.new_zeros(1)
         if not for_discriminator:
-            disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_iter_start)
-            rec_loss = self.pixel_loss(input_frames, recon_frames) if self.pixel_weight > 0 else zero
-            if self.perceptual_weight > 0:
-                p_loss = self.perceptual_loss(input_frames, recon_frames)
-            else:
-                p_loss = zero
+            disc_factor = _started(self.disc_factor, global_step, self.discriminator_iter_start)
+            rec_loss = self._pixel(input_frames, recon_frames) if self.pixel_weight > 0 else zero
+            p_loss = self._perceptual(input_frames, recon_frames) if self.perceptual_weight > 0 else zero
             nll_loss = torch.mean(self.pixel_weight * rec_loss + self.perceptual_weight * p_loss)
             if disc_factor > 0.0:
                 logits_fake = self.discriminator(reconstructions)
-                g_loss = self.g_loss(logits_fake)
+                g_loss = self.objective.generator(logits_fake)
                 d_weight = self.discriminator_weight
             else:
                 d_weight, g_loss = 0.0, zero
@@ -249,7 +247,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
             info = {"rec_loss": rec_loss.mean().detach(), "perceptual_loss": p_loss.mean().detach(), "rp_loss": nll_loss.detach(),
                     "g_loss": g_loss.mean().detach(), "g_loss_weight": g_loss_weight}
             return loss, info, 0
-        disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_self_start)
+        disc_factor = _started(self.disc_factor, global_step, self.discriminator_self_start)
         if disc_factor > 0.0:
             # one pass over [real ; fake]: the discriminator has no batch-coupled op (LayerNorm and attention are per
             # clip), so this equals the reference's two calls (:417-424) and halves the launches
@@ -257,12 +255,11 @@ class VQLPIPSWithDiscriminator(nn.Module):
             logits = self.discriminator(torch.cat([inputs, reconstructions.detach()], dim=0))
             logits_real, logits_fake = logits[:nb], logits[nb:]
             if self.lecam_weight > 0.0:
-                lecam_loss = self.lecam_weight * lecam_reg(real_pred=logits_real.mean(), fake_pred=logits_fake.mean(),
-                                                           ema_real_pred=self.lecam_ema_real, ema_fake_pred=self.lecam_ema_fake)
+                lecam_loss = self.lecam_weight * _lecam(logits_real.mean(), logits_fake.mean(), self.lecam_ema_real, self.lecam_ema_fake)
                 self.update_lecam_ema(logits_real, logits_fake)
             else:
                 lecam_loss = zero
-            d_loss = self.disc_loss(logits_real, logits_fake)
+            d_loss = self.objective.discriminator(logits_real, logits_fake)
             total_loss = d_loss + self.lecam_weight * lecam_loss     # (sic) the reference applies lecam_weight twice, loss.py:426-437
         else:
             d_loss = lecam_loss = total_loss = logits_real = logits_fake = zero
