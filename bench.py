@@ -398,6 +398,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(loss).item(), "loss is not finite"
+    for st in model._engine.states.values():     # every hand-off of the attention backward completed (sticky status word)
+        st.check_status(wait=True)
     # host-side cost of ENQUEUEING one step, measured outside the timed region on an empty queue (a sync before each probe
     # step): inside the timed loop the host runs ahead until the HIP queue is full and then measures back-pressure instead
     host = []

@@ -199,14 +199,16 @@ int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO
  * across the key blocks of a head by an ordered hand-off through `ws` (fixed summation order: results are bit-reproducible
  * run to run; no atomics on data).  `ws` (vt_attention_bwd_fused_workspace_bytes, 16-byte aligned) holds the fp32 partial
  * sums, the arrival counters and a status word; the call zeroes its control block itself (graph-capturable, nothing
- * allocates or synchronises).  Every in-kernel wait is bounded: if one gives up, the kernel still terminates and
- * vt_attention_bwd_fused_status (which synchronises the stream) reports status != 0 -- the outputs are then invalid.
+ * allocates or synchronises); the caller zeroes the whole workspace ONCE before its first use.  Every in-kernel wait is
+ * bounded: if one gives up, the kernel still terminates and sets the STICKY status word (the last 16 bytes of `ws`;
+ * vt_attention_bwd_fused_status reads it and synchronises the stream): != 0 means the outputs of some launch on this
+ * workspace are invalid.
  * Replaces autograd of F.scaled_dot_product_attention under models/transformer.py:52-59. */
 size_t vt_attention_bwd_fused_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t hd, int32_t q_begin);
 int vt_attention_bwd_fused(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
                            int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, void* ws, size_t ws_bytes,
                            vtStream stream);
-int vt_attention_bwd_fused_status(const void* ws, int32_t* status, vtStream stream);
+int vt_attention_bwd_fused_status(const void* ws, size_t ws_bytes, int32_t* status, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vector quantisation (SimpleVectorQuantizer.forward, models/bottleneck.py:262-324).
@@ -429,6 +431,8 @@ int vt_tokenizer_codes_to_encoded(vtTokenizer* tk, const vtTokenizerTensors* par
  * may become final a few stages later: *final_through (optional) receives the number of leading stages
  * whose gradients are complete once the enqueued work has run. */
 int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* tk);
+/* byte offset inside the workspace of the attention backward's sticky status word (see vt_attention_bwd_fused), 0 if unused */
+size_t vt_tokenizer_status_offset(const vtTokenizer* tk);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);

@@ -246,6 +246,8 @@ def _grads_of(model, x, w, q_weight):
     out = model(x)
     ((out["pred_frames"] * w).sum() + q_weight * out["loss_q"]).backward()
     torch.cuda.synchronize()
+    for st in model._engine.states.values():       # the attention backward's ordered hand-offs all completed
+        st.check_status(wait=True)
     return out, {n: p.grad.clone() for n, p in model.named_parameters()}
 
 

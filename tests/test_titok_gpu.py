@@ -301,6 +301,49 @@ def test_first_token_registry_names_resolve_and_run_at_the_reference_geometry(vt
         assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
 
 
+def test_packed_weights_follow_the_module_not_the_address(vt, monkeypatch):
+    """Round-2 advisor finding: the pooled GatedStack workspaces are keyed by geometry and held packed bf16 weights identified
+    only by (parameter address, _version).  A second model of the same geometry built after the first was deleted gets the same
+    addresses from the caching allocator and the same version counters -- and used to run on the FIRST model's matrices.  The key
+    now carries the owning module's identity: model B must equal its own per-layer composition (VT_GATED_PYTHON=1) bit for
+    bit.  `p.data.copy_` does not bump `_version`: after vt.invalidate_weight_packs(model) the copies are re-made."""
+    cos, sin = vt.titok.rope_tables(32, [2, 4, 4])
+    fr = (cos.cuda(), sin.cuda())
+    x = torch.from_numpy(gen.normal((2, 64, 256), 911, 0.5)).cuda()
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        blk = vt.titok.ResidualAttentionBlock(256, 4, 4, 3).cuda()
+        for p_ in blk.parameters():
+            if p_.dim() > 1:
+                torch.nn.init.normal_(p_, 0.0, 0.05)
+        return blk
+
+    monkeypatch.setenv("VT_GATED_PYTHON", "0")
+    a = fresh(1)
+    with torch.no_grad():
+        out_a = a(x, fr).clone()
+    ptrs_a = [p_.data_ptr() for p_ in a.parameters()]
+    del a
+    torch.cuda.synchronize()
+    b = fresh(2)
+    same_addresses = [p_.data_ptr() for p_ in b.parameters()] == ptrs_a     # the situation the finding describes (usual, not guaranteed)
+    with torch.no_grad():
+        out_b = b(x, fr).clone()
+        monkeypatch.setenv("VT_GATED_PYTHON", "1")
+        ref_b = b(x, fr).clone()
+        monkeypatch.setenv("VT_GATED_PYTHON", "0")
+    assert torch.equal(out_b, ref_b), f"model B ran on stale packed weights (same addresses: {same_addresses})"
+    assert not torch.equal(out_b, out_a)
+    with torch.no_grad():
+        b.attn_layer[0].to_qkv.weight.data.copy_(b.attn_layer[0].to_qkv.weight.data * 1.5)    # no _version bump
+        vt.invalidate_weight_packs(b)
+        out_c = b(x, fr).clone()
+        monkeypatch.setenv("VT_GATED_PYTHON", "1")
+        ref_c = b(x, fr).clone()
+    assert torch.equal(out_c, ref_c) and not torch.equal(out_c, out_b)
+
+
 def test_gated_stack_engine_equals_python_composition(vt, monkeypatch):
     """vt_gated_stack_forward / _backward (one C++ enqueue per direction) == the per-layer Python composition of the same
     kernels (titok.GatedLayer), bit for bit: output, input gradient and every parameter gradient of a 4-layer stack, incl.

@@ -12,3 +12,16 @@ from .larp_tokenizer import LARPTokenizer  # noqa: F401
 from .larp_ar import LARP_AR  # noqa: F401
 from .loss import TransformerDiscriminator, VQLPIPSWithDiscriminator  # noqa: F401
 from .fsq import FSQ  # noqa: F401
+
+
+def invalidate_weight_packs(module):
+    """Drop every cached bf16 operand copy below `module`.  The copies are keyed by (owner identity, parameter address,
+    `_version`); optimizer steps, load_state_dict and .to() change one of these, a write through `.data` (`p.data.copy_(...)`,
+    e.g. a hand-rolled EMA swap) does not -- call this after such a write."""
+    for m in module.modules():
+        if hasattr(m, "invalidate_packs"):
+            m.invalidate_packs()
+        m.__dict__.pop("_vt_pack", None)                      # larp_ar._pack caches
+        eng = m.__dict__.get("_engine")
+        if eng is not None:
+            eng.param_epoch = getattr(eng, "param_epoch", 0) + 1   # the tokenizer engine re-packs on the next forward

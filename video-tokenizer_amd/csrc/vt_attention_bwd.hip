@@ -42,11 +42,11 @@ namespace {
 
 constexpr int FB_T = 8192;                       // bytes of a [64][64] bf16 tile
 constexpr int FB_KIMG = 0;                       // K image of the 256 own keys: 4 tiles
-constexpr int FB_QBUF = 4 * FB_T;                // 2 x (Q tile | dO tile | lse2[64] | delta[64])
+constexpr int FB_VIMG = 4 * FB_T;                // V image of the same keys (B operands of dP are read from here, not held in registers)
+constexpr int FB_QBUF = 8 * FB_T;                // 2 x (Q tile | dO tile | lse2[64] | delta[64])
 constexpr int FB_QSZ = 2 * FB_T + 512;
 constexpr int FB_DS = FB_QBUF + 2 * FB_QSZ;      // dS^T image [256 keys][64 queries]
-constexpr int FB_PBUF = FB_DS + 4 * FB_T;        // predecessor's partial sum: 4 tiles x 4 KB fp32
-constexpr int FB_XBUF = FB_PBUF + 16384;         // waves 4-7 -> waves 0-3
+constexpr int FB_XBUF = FB_DS + 4 * FB_T;        // waves 4-7 -> waves 0-3: 4 tiles x 4 KB fp32
 constexpr int FB_MISC = FB_XBUF + 16384;         // work-queue ticket broadcast
 constexpr int FB_LDS = FB_MISC + 16;
 
@@ -64,11 +64,35 @@ struct FusedBwdArgs {
     float scale, scale_log2e;
 };
 
+// Diagnostic build only (-DFB_STAMPS, tools/fb_stamps.sh): s_memtime stamps around the segments of an iteration, summed per wave
+// into a buffer of their own.  In the real kernel no stamp executes; the diagnostic build's run time is never quoted.
+#ifdef FB_STAMPS
+__device__ unsigned long long fb_dbg[2048 * 8];
+#define FB_STAMP(k)                                                                   \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        unsigned long long t__;                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        fb_acc[k] += t__ - fb_last;                                                   \
+        fb_last = t__;                                                                \
+    } while (0)
+#else
+#define FB_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz
 
 // 16-byte write-through store (sc1): leaves the XCD's L2 for the memory side, so a consumer on any XCD reads it after its acquire
 __device__ __forceinline__ void st_sc1(float* p, const f32x4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// workgroup barrier that leaves this wave's LDS-DMA / stores in flight (a __syncthreads() would drain vmcnt too)
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // 512 threads stage one [64][64] bf16 tile: one 16-byte LDS-DMA per thread, swizzle on the source chunk
@@ -90,15 +114,15 @@ __device__ __forceinline__ void stage512_clamped(const bf16_t* src, int64_t rs, 
 
 // phase A of one slice for one wave: S, dP, P, dS (-> LDS image), dV, dK.   TQ: mask queries >= L; TK: mask keys >= L
 template <bool TQ, bool TK>
-__device__ __forceinline__ void fb_phase_a(const char* qt_l, char* ds_l, const char* k_row, const bf16x8 (&vf)[4], f32x16 (&dk)[2], f32x16 (&dv)[2],
+__device__ __forceinline__ void fb_phase_a(const char* qt_l, char* ds_l, const char* k_row, f32x16 (&dk)[2], f32x16 (&dv)[2],
                                            int q0, int L, bool kvalid, int keyrow, float c, int lane, int half) {
     const char* do_l = qt_l + FB_T;
     const float* lse_l = (const float*)(qt_l + 2 * FB_T);
     const float* del_l = lse_l + 64;
     char* ds_row = ds_l + keyrow * 128 + 8 * half;
     const int fs = fsw<64>(keyrow);
-    // own K row as the B operand of S = Q.K^T, k-step s: B[k = 16s + 8*half + j][key] = chunk 2s + half of the K image's row
-    // (held in LDS, not in registers: the kernel sits at the 256-VGPR limit of two waves per SIMD)
+    // own K / V rows as the B operands of S = Q.K^T and dP = dO.V^T, k-step s: B[k = 16s + 8*half + j][key] = chunk 2s + half of
+    // the image's row (held in LDS, not in registers: the kernel sits at the 256-VGPR limit of two waves per SIMD)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         f32x16 sacc, dp;
@@ -107,8 +131,9 @@ __device__ __forceinline__ void fb_phase_a(const char* qt_l, char* ds_l, const c
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 kfs = *(const bf16x8*)(k_row + (((2 * s + half) ^ fs) << 4));
+            const bf16x8 vfs = *(const bf16x8*)(k_row + (FB_VIMG - FB_KIMG) + (((2 * s + half) ^ fs) << 4));
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<64>(qt_l, qt * 32, s, lane), kfs, sacc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<64>(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<64>(do_l, qt * 32, s, lane), vfs, dp, 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -153,6 +178,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
     const int dqt = wave & 1, qqt = (wave >> 1) & 1, kh = wave >> 2;     // phase B: d tile, query tile, key half of this wave
     const int xoff = ((dqt + 2 * qqt) * 4) * 1024 + lane * 16;            // this wave's tile in pbuf / xbuf / P (fragment order)
     const unsigned long long t_start = realtime();
+#ifdef FB_STAMPS
+    unsigned long long fb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fb_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fb_last)::"memory");
+#endif
     constexpr unsigned long long SPIN_LIMIT = 30000000ull;                // 0.3 s of 100 MHz ticks: bounded spins
 
     for (;;) {
@@ -179,19 +208,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
         const bool ragged_k = key_base + 256 > L;          // workgroup-uniform
         const int keyrow = wave * 32 + (lane & 31);         // row in the K / dS images
 
-        bf16x8 vf[4];
-        load_own<4>(vbp, rs, k0, L, lane, vf);
         f32x16 dk[2], dv[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
 
-        // K image: 4 tiles of 64 keys (rows past L clamped: their dS columns are zero)
+        // K and V images: 4 tiles of 64 keys each (rows past L clamped: their P / dS columns are zero)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (key_base + 64 * j + 64 <= L) stage512_full(kbp + (int64_t)(key_base + 64 * j) * rs, qoff, sbase + FB_KIMG + j * FB_T, wave);
-            else stage512_clamped(kbp, rs, key_base + 64 * j, L, sbase + FB_KIMG + j * FB_T, tid, wave);
+            if (key_base + 64 * j + 64 <= L) {
+                stage512_full(kbp + (int64_t)(key_base + 64 * j) * rs, qoff, sbase + FB_KIMG + j * FB_T, wave);
+                stage512_full(vbp + (int64_t)(key_base + 64 * j) * rs, qoff, sbase + FB_VIMG + j * FB_T, wave);
+            } else {
+                stage512_clamped(kbp, rs, key_base + 64 * j, L, sbase + FB_KIMG + j * FB_T, tid, wave);
+                stage512_clamped(vbp, rs, key_base + 64 * j, L, sbase + FB_VIMG + j * FB_T, tid, wave);
+            }
         }
         const int s0 = (int)(((unsigned)kb * (unsigned)nsl) / (unsigned)nkb);    // first slice of this key block (rotated start)
         auto stage_slice = [&](int s, int buf) {
@@ -217,48 +249,61 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
             const int pos = (int)head - kb;
             return pos < 0 ? pos + nkb : pos;
         };
+        // bounded wait for the slice's arrival counter (slow path: normally the value polled an iteration ahead already suffices)
+        auto wait_counter = [&](const unsigned* c, unsigned want, unsigned have) {
+            while (have < want) {
+                have = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (have >= want) break;
+                if (realtime() - t_start > SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        };
+        // predecessor's partial sum of slice s (this wave's tile): four 16-byte sc1 (L1-bypassing) loads to registers.  No acquire:
+        // the counter was polled by an sc1 load a slice earlier, workgroup barriers lie between that poll and these loads, every
+        // byte was stored sc1 in whole 128-byte lines and drained before its wave's arrival (MI355X_MICROARCH.md, visibility,
+        // the third "valid form" row).  An acquire here (buffer_inv sc1) blocks the CU's whole vector-memory path for ~1.7 us per
+        // slice -- measured with stamps: 28 % of the kernel.
+        const auto p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Pb, 0, nsl * 16384, 0x00020000);
+        f32x4 pv[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) pv[g4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto fetch_prev = [&](int s) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                pv[g4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, xoff + g4 * 1024, s * 16384, 16));
+        };
+        auto next_slice = [&](int s) { return s + 1 >= nsl ? 0 : s + 1; };
+
+        int pos_c = chain_pos(s0);                          // this block's place in the chain of the current slice
+        int pos_n = nsl > 1 ? chain_pos(next_slice(s0)) : 0;
         stage_slice(s0, 0);
-        // poll one slice ahead: the counter value for the first slice is requested now, consumed at the top of iteration 0
         unsigned seen = 0;
-        if (kh == 1 && chain_pos(s0) > 0) seen = __hip_atomic_load(ctr_b + s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pin_loaded(vf);
+        if (kh == 1) {
+            if (pos_c > 0) {                                // only when several key blocks share a first slice (nkb > nsl)
+                wait_counter(ctr_b + s0, 4u * (unsigned)pos_c, 0u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // poll and loads not separated by a barrier: keep the acquire
+                fetch_prev(s0);
+            }
+            if (nsl > 1 && pos_n > 0) seen = __hip_atomic_load(ctr_b + next_slice(s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         dma_drain();
         __syncthreads();
 
+        int pending = -1;                                   // slice whose write-through stores are out but not yet announced
+        bool have_prev = true;                              // this slice's predecessor sum is (on its way) in pbuf[cur]
+        int s = s0;
         for (int i = 0; i < nsl; ++i) {
-            int s = s0 + i;
-            s = s >= nsl ? s - nsl : s;
-            int sn = s + 1;
-            sn = sn >= nsl ? 0 : sn;
+            const int sn = next_slice(s), sn2 = next_slice(sn);
             const int cur = i & 1;
-            const int pos = chain_pos(s);
+            const int pos = pos_c;
             const bool last = pos == nkb - 1;
-            // ---- phase A ----  (the acquire's vmcnt(0) comes first: nothing of this wave is in flight yet)
-            if (kh == 1) {
-                if (pos > 0) {      // predecessor's partial sum of this slice -> pbuf
-                    const unsigned want = 4u * (unsigned)pos;
-                    if (seen < want) {
-                        for (;;) {
-                            seen = __hip_atomic_load(ctr_b + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (seen >= want) break;
-                            if (realtime() - t_start > SPIN_LIMIT) {
-                                if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(8);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    const float* src = Pb + (int64_t)s * 4096 + (dqt + 2 * qqt) * 1024 + lane * 4;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) glds16_asm(src + g4 * 256, sbase + FB_PBUF + ((dqt + 2 * qqt) * 4 + g4) * 1024);
-                }
-            }
+            const int pos_nn = i + 2 < nsl ? chain_pos(sn2) : 0;
+            // ---- phase A: next slice's tiles on their way, S / dP / softmax / dS / dV / dK of this one ----
+            FB_STAMP(7);
             if (i + 1 < nsl) stage_slice(sn, cur ^ 1);
-            if (kh == 1) {      // next slice's counter, consumed an iteration from now
-                seen = 0;
-                if (i + 1 < nsl && chain_pos(sn) > 0) seen = __hip_atomic_load(ctr_b + sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             {
                 int lane_a = lane;
                 asm volatile("" : "+v"(lane_a));
@@ -268,29 +313,42 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
                 const char* k_row = smem + FB_KIMG + keyrow_a * 128;
                 const int q0 = a.q_begin + 64 * s;
                 const bool tq = q0 + 64 > L;
-                if (!tq && !ragged_k) fb_phase_a<false, false>(qt_l, smem + FB_DS, k_row, vf, dk, dv, q0, L, kvalid, keyrow_a, a.scale_log2e, lane_a, half_a);
-                else if (!tq) fb_phase_a<false, true>(qt_l, smem + FB_DS, k_row, vf, dk, dv, q0, L, kvalid, keyrow_a, a.scale_log2e, lane_a, half_a);
-                else fb_phase_a<true, true>(qt_l, smem + FB_DS, k_row, vf, dk, dv, q0, L, kvalid, keyrow_a, a.scale_log2e, lane_a, half_a);
+                if (!tq && !ragged_k) fb_phase_a<false, false>(qt_l, smem + FB_DS, k_row, dk, dv, q0, L, kvalid, keyrow_a, a.scale_log2e, lane_a, half_a);
+                else if (!tq) fb_phase_a<false, true>(qt_l, smem + FB_DS, k_row, dk, dv, q0, L, kvalid, keyrow_a, a.scale_log2e, lane_a, half_a);
+                else fb_phase_a<true, true>(qt_l, smem + FB_DS, k_row, dk, dv, q0, L, kvalid, keyrow_a, a.scale_log2e, lane_a, half_a);
             }
-            dma_drain();
-            __syncthreads();
+            FB_STAMP(0);
+            if (kh == 0 && pending >= 0) {
+                // announce the previous slice: its write-through stores were issued a whole phase ago, so this drain does not
+                // stall, and it comes BEFORE any wait of this iteration (a block never waits while it owes an announcement:
+                // the dependency order of the chains stays the acyclic one of the header comment)
+                dma_drain();
+                if (lane == 0) __hip_atomic_fetch_add(ctr_b + pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pending = -1;
+            }
+            FB_STAMP(1);
+            wg_barrier();                                   // dS image complete
+            FB_STAMP(2);
             // ---- phase B: dQ^T tile of this wave over its 128-key half ----
             // (lane made opaque per phase: hipcc otherwise hoists every fragment address of both phases out of the slice loop
             //  and holds ~40 of them across phase A, which is already at the register limit)
             int lane_b = lane;
             asm volatile("" : "+v"(lane_b));
             f32x16 dq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
             if (kh == 1 && pos > 0) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 v = *(const f32x4*)(smem + FB_PBUF + xoff + g4 * 1024);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dq[4 * g4 + e] = v[e];
+                if (!have_prev) {                           // slow path: the predecessor was not done when we looked a slice ago
+                    wait_counter(ctr_b + s, 4u * (unsigned)pos, 0u);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    fetch_prev(s);
                 }
-            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq[4 * g4 + e] = pv[g4][e];
             }
+            FB_STAMP(3);
 #pragma unroll
             for (int sp = 0; sp < 8; ++sp)
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<64>(smem + FB_KIMG, 128 * kh, sp, 32 * dqt, lane_b),
@@ -304,7 +362,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
                     *(f32x4*)(smem + FB_XBUF + xoff + g4 * 1024) = v;
                 }
             }
-            __syncthreads();
+            dma_drain();                                    // own LDS-DMA of the next slice's tiles landed (kh == 0: and the previous
+                                                            // slice's write-through stores are out)
+            if (kh == 1) {
+                // the NEXT slice's predecessor sum, if its counter (polled a slice ago) already says so: a whole iteration to arrive
+                have_prev = false;
+                if (i + 1 < nsl && pos_n > 0 && seen >= 4u * (unsigned)pos_n) {
+                    fetch_prev(sn);
+                    have_prev = true;
+                }
+                seen = 0;
+                if (i + 2 < nsl && pos_nn > 0) seen = __hip_atomic_load(ctr_b + sn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            FB_STAMP(4);
+            wg_barrier();
+            FB_STAMP(5);
             if (kh == 0) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -324,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
                             *(bf16x4*)(p + 8 * g4) = v;
                         }
                     }
-                } else {        // publish: write-through stores, drain, one arrival per storing wave
+                } else {        // write-through stores now, the announcement after the next phase A (their latency stays off the critical path)
                     float* dst = Pb + (int64_t)s * 4096 + (dqt + 2 * qqt) * 1024 + lane * 4;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -333,16 +405,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
                         for (int e = 0; e < 4; ++e) v[e] = dq[4 * g4 + e];
                         st_sc1(dst + g4 * 256, v);
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_fetch_add(ctr_b + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pending = s;
                 }
             }
+            FB_STAMP(6);
+            pos_c = pos_n;
+            pos_n = pos_nn;
+            s = sn;
+        }
+        if (kh == 0 && pending >= 0) {
+            dma_drain();
+            if (lane == 0) __hip_atomic_fetch_add(ctr_b + pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- dK (scaled), dV of the own keys ----
         bf16_t* dkb = a.dqkv + (int64_t)b * L * rs + (int64_t)h * 64 + (int64_t)H * 64;
         store_own<2>(dk, a.scale, dkb, rs, key, kvalid, half);
         store_own<2>(dv, 1.0f, dkb + (int64_t)H * 64, rs, key, kvalid, half);
     }
+#ifdef FB_STAMPS
+    if (lane == 0 && blockIdx.x < 256)
+        for (int k = 0; k < 8; ++k) fb_dbg[(blockIdx.x * 8 + wave) * 8 + k] = fb_acc[k];
+#endif
 }
 
 // delta[b, h, q] = sum_d dO[b, q - q_begin, h, d] * O[...]: 8 lanes x 16 bytes per (row, head)
@@ -383,7 +466,7 @@ __global__ void zero_q_rows_kernel2(bf16_t* __restrict__ dqkv, int L, int q_begi
 
 struct FusedPlan {
     int nkb, nsl, nitems;
-    size_t p_bytes, ctr_off, ctr_bytes, total;
+    size_t p_bytes, ctr_off, ctr_bytes, status_off, total;
 };
 FusedPlan fused_plan(int B, int L, int H, int q_begin) {
     FusedPlan p;
@@ -391,10 +474,13 @@ FusedPlan fused_plan(int B, int L, int H, int q_begin) {
     p.nsl = (L - q_begin + 63) / 64;
     p.nitems = B * H * p.nkb;
     p.p_bytes = (size_t)B * H * p.nsl * 16384;
-    // control block first (zeroed per launch, a multiple of 16 bytes): [ticket, status, pad, pad][counters]
+    // control block first (zeroed per launch, a multiple of 16 bytes): [ticket, pad, pad, pad][counters]; then the partial sums;
+    // the STICKY status word is the last 16 bytes of the caller's workspace (set by a kernel whose bounded spin gave up, never
+    // cleared by a launch: the caller zeroes the workspace once, vt_attention_bwd_fused_status / the engine read it at leisure)
     p.ctr_bytes = (((size_t)B * H * p.nsl * 4 + 16) + 15) / 16 * 16;
     p.ctr_off = 0;
-    p.total = p.ctr_bytes + p.p_bytes;
+    p.status_off = p.ctr_bytes + p.p_bytes;
+    p.total = p.status_off + 16;
     return p;
 }
 
@@ -402,7 +488,7 @@ FusedPlan fused_plan(int B, int L, int H, int q_begin) {
 
 static const int g_cu_count = [] {
     int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
     return n > 0 ? n : 256;
 }();
 
@@ -441,8 +527,8 @@ extern "C" int vt_attention_bwd_fused(const void* qkv, const void* o_compact, co
     a.dqkv = (bf16_t*)dqkv;
     unsigned* ctl = (unsigned*)ws;
     a.ticket = ctl;
-    a.status = ctl + 1;
     a.ctr = ctl + 4;
+    a.status = (unsigned*)((char*)ws + (ws_bytes / 16) * 16 - 16);   // the LAST 16 bytes of whatever the caller supplied
     a.P = (float*)((char*)ws + p.ctr_bytes);
     a.L = L;
     a.H = H;
@@ -454,7 +540,10 @@ extern "C" int vt_attention_bwd_fused(const void* qkv, const void* o_compact, co
     a.scale_log2e = 0.125f * 1.44269504088896340736f;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+        if (hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS) != hipSuccess) {
+            vt_set_error("vt_attention_bwd_fused: hipFuncSetAttribute(%d bytes of LDS) failed", FB_LDS);
+            return VT_ERR_LAUNCH;
+        }
         attr_set = true;
     }
     const int grid = p.nitems < g_cu_count ? p.nitems : g_cu_count;
@@ -463,14 +552,21 @@ extern "C" int vt_attention_bwd_fused(const void* qkv, const void* o_compact, co
     return VT_OK;
 }
 
-// status word of the last launch on this workspace (0 = ok); synchronises the stream
-extern "C" int vt_attention_bwd_fused_status(const void* ws, int32_t* status, vtStream stream) {
-    VT_CHECK_ARG(ws && status, "vt_attention_bwd_fused_status: null pointer");
+// sticky status word of this workspace = its last 16 bytes (0 = no bounded spin ever gave up); synchronises the stream
+extern "C" int vt_attention_bwd_fused_status(const void* ws, size_t ws_bytes, int32_t* status, vtStream stream) {
+    VT_CHECK_ARG(ws && status && ws_bytes >= 32, "vt_attention_bwd_fused_status: bad argument");
     unsigned v = 0;
-    if (hipMemcpyAsync(&v, (const char*)ws + 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    if (hipMemcpyAsync(&v, (const char*)ws + (ws_bytes / 16) * 16 - 16, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
         vt_set_error("vt_attention_bwd_fused_status: copy failed");
         return VT_ERR_LAUNCH;
     }
     *status = (int32_t)v;
     return VT_OK;
 }
+
+#ifdef FB_STAMPS
+extern "C" int vt_attention_bwd_fused_stamps(unsigned long long* host_out) {   // [256 workgroups][8 waves][8 segments] cycles
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fb_dbg), sizeof(unsigned long long) * 2048 * 8) == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+#endif

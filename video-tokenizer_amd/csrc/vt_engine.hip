@@ -84,6 +84,7 @@ struct vtTokenizer {
     size_t hN, meanH, rstdH, yrows;
     // backward scratch
     size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
+    size_t attn_ws = 0, attn_ws_bytes = 0;   // five-product attention backward: partial dQ sums + hand-off counters (head_dim 64)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
     // is the next block's dx_out set).
@@ -194,6 +195,8 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
         lb.dxa = a.take((size_t)lb.Mkp * D * 2); lb.dxm = a.take((size_t)lb.Mkp * D * 2); lb.du = a.take((size_t)lb.Mkp * t->D4 * 2);
     }
     t->delta = a.take((size_t)c.B * c.H * t->L * 4);
+    t->attn_ws_bytes = vt_attention_bwd_fused_workspace_bytes(c.B, t->L, c.H, c.D / c.H, 0);   // q_begin = 0 is the largest plan
+    t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
     t->cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);  // per-M-tile column sums out of the fc2-dgrad epilogue
@@ -210,6 +213,11 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
 extern "C" void vt_tokenizer_destroy(vtTokenizer* t) { delete t; }
 extern "C" size_t vt_tokenizer_workspace_bytes(const vtTokenizer* t) { return t ? t->ws_bytes : 0; }
 extern "C" int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* t) { return t ? 3 + t->c.depth_enc + t->c.depth_dec : 0; }
+// byte offset inside the workspace of the attention backward's sticky status word (vt_attention_bwd_fused), 0 if that kernel is not in use
+extern "C" size_t vt_tokenizer_status_offset(const vtTokenizer* t) {
+    if (!t || !t->attn_ws_bytes) return 0;
+    return t->attn_ws + (t->attn_ws_bytes / 16) * 16 - 16;
+}
 
 extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream stream) {
     VT_CHECK_ARG(t && ws, "vt_tokenizer_init_workspace: null pointer");
@@ -220,6 +228,16 @@ extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream st
         return VT_ERR_LAUNCH;
     }
     return VT_OK;
+}
+
+// Attention backward of one block: the five-product kernel with the ordered dQ hand-off where it exists (head_dim 64), the
+// two-kernel form otherwise (the discriminator's head_dim 32) or on request (VT_ATTN_BWD=split, read once: A/B timing in tools/).
+static const bool g_attn_bwd_split = [] { const char* e = getenv("VT_ATTN_BWD"); return e && strcmp(e, "split") == 0; }();
+static int attn_bwd(vtTokenizer* t, void* ws, const void* qkv, const void* o, const void* dO, const float* lse, int q_begin, void* dqkv, vtStream s) {
+    const vtTokenizerConfig& c = t->c;
+    if (t->attn_ws_bytes && !g_attn_bwd_split)
+        return vt_attention_bwd_fused(qkv, o, dO, lse, c.B, t->L, c.H, c.D / c.H, q_begin, dqkv, WS(float, t->delta), WS(void, t->attn_ws), t->attn_ws_bytes, s);
+    return vt_attention_bwd_rows(qkv, o, dO, lse, c.B, t->L, c.H, c.D / c.H, q_begin, dqkv, WS(float, t->delta), s);
 }
 
 static int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
@@ -511,7 +529,7 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     g = nt(dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
     // attention backward
-    TRY(vt_attention_bwd(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, c.D / c.H, dqkv, WS(float, t->delta), s));
+    TRY(attn_bwd(t, ws, WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), 0, dqkv, s));
     // qkv dgrad
     g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
@@ -559,8 +577,7 @@ static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb,
     TRY(vt_cast_rows(dX, kmap, Mk, D, dXm, D, s));
     g = nt(dXm, D, WS(void, b.proj_wt), D, Mk, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
-    TRY(vt_attention_bwd_rows(WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), c.B, t->L, c.H, c.D / c.H, lb.q_begin, dqkv,
-                              WS(float, t->delta), s));
+    TRY(attn_bwd(t, ws, WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), lb.q_begin, dqkv, s));
     g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     t->pending.push_back(tn(dXa, D, WS(void, b.g), D4, Mkp, D, D4, gr.fc2_w, D4));
@@ -707,6 +724,8 @@ extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
     }
     t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
     t->delta = a.take((size_t)B * H * L * 4);
+    t->attn_ws_bytes = vt_attention_bwd_fused_workspace_bytes(B, L, H, D / H, 0);   // 0 when head_dim != 64: two-kernel backward
+    t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes(t->D4));
     t->cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);

@@ -107,6 +107,29 @@ class _State:
         self.nstages = hip.lib().vt_tokenizer_num_backward_stages(h)
         self.packed_version = None
         self.fwd_id = 0
+        # the attention backward's hand-off waits are bounded; a wait that gave up leaves a sticky status word in the workspace.
+        # It is copied to pinned host memory behind every backward and looked at before the next one: a failure is reported one
+        # step late, loudly, without ever synchronising the stream.
+        off = hip.lib().vt_tokenizer_status_offset(h)
+        self.status_dev = self.ws[off:off + 4].view(torch.int32) if off else None
+        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory() if off else None
+        self.status_event = None
+
+    def check_status(self, wait=False):
+        if self.status_dev is None or self.status_event is None:
+            return
+        if wait:
+            self.status_event.synchronize()
+        if self.status_event.query() and int(self.status_host[0]) != 0:
+            raise hip.HipError("attention backward: an inter-workgroup hand-off timed out (status word set); the gradients of that "
+                               "step are invalid")
+
+    def post_status(self):
+        if self.status_dev is None:
+            return
+        self.status_host.copy_(self.status_dev, non_blocking=True)
+        self.status_event = torch.cuda.Event()
+        self.status_event.record()
 
     def __del__(self):
         try:
@@ -290,6 +313,7 @@ class TokenizerFunction(torch.autograd.Function):
             raise hip.HipError("LARPTokenizer.backward: the engine workspace was overwritten by a later forward with the same "
                                "geometry; run backward before the next forward")
         dev = st.ws.device
+        st.check_status()
         engine.ensure_flat_grad(dev)
         if d_pred is None:
             d_pred = torch.zeros(ctx.x_shape, device=dev, dtype=torch.float32)
@@ -320,6 +344,7 @@ class TokenizerFunction(torch.autograd.Function):
                 done += 1
         if red is not None:
             red.finish()
+        st.post_status()
         grads = []
         # autograd wants gradients in the order the parameters were passed to apply().  NOTE for callers: except in the aliased
         # case these are views of ONE reused buffer -- the next backward of this model overwrites them.

@@ -68,7 +68,7 @@ SIGNATURES = {
     "vt_attention_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_bwd_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "vt_attention_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "vt_attention_bwd_fused_status": (c_i32, [c_vp, ctypes.POINTER(c_i32), c_vp]),
+    "vt_attention_bwd_fused_status": (c_i32, [c_vp, c_sz, ctypes.POINTER(c_i32), c_vp]),
     "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -170,6 +170,7 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_decode": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_codes_to_encoded": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_num_backward_stages": (c_i32, [c_vp]),
+    "vt_tokenizer_status_offset": (c_sz, [c_vp]),
     "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, ctypes.POINTER(c_i32), c_vp]),
 }
 
@@ -378,7 +379,7 @@ def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0, fused=
         n = lib().vt_attention_bwd_fused_workspace_bytes(B, L, H, hd, q_begin)
         if n == 0:
             raise HipError(f"vt_attention_bwd_fused: unsupported geometry B={B} L={L} H={H} hd={hd} q_begin={q_begin}")
-        ws = _ws(n, qkv.device)
+        ws = torch.zeros(n, dtype=torch.uint8, device=qkv.device)     # zeroed once: the status word is sticky
         check(lib().vt_attention_bwd_fused(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), ptr(ws), n, stream()),
               "vt_attention_bwd_fused")
         attention_bwd.last_ws = ws
@@ -388,9 +389,9 @@ def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0, fused=
 
 
 def attention_bwd_fused_status(ws):
-    """status word of the last fused backward on this workspace (synchronises the stream): 0 = every hand-off completed"""
+    """sticky status word of a fused-backward workspace (`attention_bwd.last_ws`; synchronises the stream): 0 = every hand-off completed"""
     st = c_i32(0)
-    check(lib().vt_attention_bwd_fused_status(ptr(ws), ctypes.byref(st), stream()), "vt_attention_bwd_fused_status")
+    check(lib().vt_attention_bwd_fused_status(ptr(ws), ws.numel(), ctypes.byref(st), stream()), "vt_attention_bwd_fused_status")
     return st.value
 
 

@@ -63,6 +63,7 @@ class LARPTokenizer(nn.Module):
         extra["bottleneck_norm"] = bn is not None and str(bn).lower() not in ("no", "none")
         extra["entropy_loss"] = bottleneck_type == "vq" and float(bottleneck["args"]["regularizer"]["args"].get("entropy_loss_weight", 0.0)) > 0
         self._composed = bottleneck_type == "fsq" or any(extra.values())
+        self._composed_why = ", ".join((["bottleneck_type='fsq'"] if bottleneck_type == "fsq" else []) + [k for k, v in extra.items() if v])
         assert temporal_patch_size >= 1
         assert (temporal_patch_size, patch_size) == (decoder_temporal_patch_size, decoder_patch_size), \
             "unpatchify uses the ENCODER patch sizes (larp_tokenizer.py:447-449): encoder and decoder patch sizes must match"

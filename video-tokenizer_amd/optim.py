@@ -13,14 +13,20 @@ from . import hip
 from .engine import _flat_order
 
 
+def _composed_reason(model):
+    """which constructor option sent the model to the composed path (LARPTokenizer records it), for error messages"""
+    why = getattr(model, "_composed_why", None)
+    return f" because of {why}" if why else ""
+
+
 def flatten_parameters(model):
     """Move every trainable parameter of `model` into one flat fp32 buffer (same order as the flat gradient
     buffer).  Parameters keep their identity (only `.data` is re-pointed), so optimizers, state_dict and DDP
     wrappers created before or after keep working.  Idempotent."""
     eng = model._engine
     if eng is None:
-        raise NotImplementedError("FusedAdam works on the fused engine's flat buffers; this model (bottleneck_type 'fsq') is composed of separate autograd "
-                                  "functions: use torch.optim.Adam")
+        raise NotImplementedError("this model runs on the composed path (no fused engine, hence no flat parameter / gradient buffers)"
+                                  + _composed_reason(model) + ": use torch.optim.Adam / torch DDP")
     if getattr(eng, "flat_param", None) is not None and eng.flat_param.device == next(model.parameters()).device:
         return eng.flat_param
     order = _flat_order(model)
@@ -45,12 +51,13 @@ class FusedAdam:
 
     def __init__(self, model, lr=1e-4, betas=(0.5, 0.9), eps=1e-8, weight_decay=0.0, ema_decay=None):
         if getattr(model, "_engine", None) is None:
-            raise NotImplementedError("FusedAdam works on the fused engine's flat buffers; this model (bottleneck_type 'fsq') is composed of separate "
-                                      "autograd functions: use torch.optim.Adam")
+            raise NotImplementedError("FusedAdam works on the fused engine's flat buffers; this model runs on the composed path"
+                                      + _composed_reason(model) + ": use torch.optim.Adam")
         self.model = model
         self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}]
         self.ema_decay = ema_decay
-        self.step_count = 0
+        self.step_count = 0          # the largest per-parameter step (torch.optim.Adam keeps one `step` per parameter)
+        self.steps = {}              # name -> steps taken by that parameter: one frozen at first and unfrozen later starts at 1
         self.m = self.v = self.ema = None
 
     def _ensure(self):
@@ -74,10 +81,12 @@ class FusedAdam:
                 view = eng.grad_views[name]
                 if p.grad.data_ptr() != view.data_ptr():
                     view.copy_(p.grad.reshape(view.shape))
-                if runs and runs[-1][1] == off:
+                k = self.steps.get(name, 0) + 1        # bias correction uses THIS parameter's step count, as torch.optim.Adam does
+                self.steps[name] = k
+                if runs and runs[-1][1] == off and runs[-1][2] == k:
                     runs[-1][1] = off + n
                 else:
-                    runs.append([off, off + n])
+                    runs.append([off, off + n, k])
             off += n
         return runs, off
 
@@ -90,40 +99,40 @@ class FusedAdam:
         g = eng.flat_grad
         assert g.numel() == flat.numel(), "flat gradient and parameter buffers must have the same (padded) length"
         grp = self.param_groups[0]
-        self.step_count += 1
         runs, total = self._active_runs(eng)
+        self.step_count = max([self.step_count] + [k for _, _, k in runs])
         if runs and runs[-1][1] == total:
             runs[-1][1] = flat.numel()          # the zero padding behind the last parameter rides along (n % 4 == 0)
         lr, (b1, b2), eps, wd = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]
         covered = 0
-        for lo, hi in runs:
+        for lo, hi, k in runs:
             # every parameter of this model has a multiple of 4 elements, so runs start and end on 16-byte boundaries; a
             # model that breaks this gets the unaligned edge elements from the same formula in torch ops on the device
             a, b = (lo + 3) // 4 * 4, hi // 4 * 4
             for (x, y) in ((lo, min(a, hi)), (max(b, a), hi)):
                 if y > x:
-                    self._adam_slice_torch(flat, g, x, y, lr, b1, b2, eps, wd)
+                    self._adam_slice_torch(flat, g, x, y, lr, b1, b2, eps, wd, k)
             if b > a:
                 ema = self.ema[a:b] if self.ema is not None else None
                 hip.check(hip.lib().vt_adam_step(hip.ptr(flat[a:b]), hip.ptr(g[a:b]), hip.ptr(self.m[a:b]), hip.ptr(self.v[a:b]), b - a, lr, b1, b2,
-                                                 eps, wd, self.step_count, hip.ptr(ema), float(self.ema_decay or 0.0), hip.stream()), "vt_adam_step")
+                                                 eps, wd, k, hip.ptr(ema), float(self.ema_decay or 0.0), hip.stream()), "vt_adam_step")
             covered += hi - lo
         if self.ema is not None and covered < flat.numel():
             # update_ema (base_trainer.py:769-779) runs over EVERY parameter, frozen ones included: their EMA keeps relaxing
             # towards the (unchanged) weight.  Frozen slices: ema = d * ema + (1 - d) * p, outside the fused launch.
             d, prev = float(self.ema_decay), 0
-            for lo, hi in runs + [[flat.numel(), flat.numel()]]:
+            for lo, hi, _ in runs + [[flat.numel(), flat.numel(), 0]]:
                 if lo > prev:
                     self.ema[prev:lo].mul_(d).add_(flat[prev:lo], alpha=1.0 - d)
                 prev = hi
         eng.param_epoch = getattr(eng, "param_epoch", 0) + 1  # the kernel wrote the weights behind torch's version counters:
         #                                                          tell the engine to re-pack its bf16 operand copies
 
-    def _adam_slice_torch(self, flat, g, x, y, lr, b1, b2, eps, wd):
+    def _adam_slice_torch(self, flat, g, x, y, lr, b1, b2, eps, wd, k):
         gg = g[x:y] + wd * flat[x:y]
         self.m[x:y].mul_(b1).add_(gg, alpha=1.0 - b1)
         self.v[x:y].mul_(b2).addcmul_(gg, gg, value=1.0 - b2)
-        bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        bc1, bc2 = 1.0 - b1 ** k, 1.0 - b2 ** k
         flat[x:y].sub_((lr / bc1) * self.m[x:y] / (self.v[x:y].sqrt() / bc2 ** 0.5 + eps))
         if self.ema is not None:
             d = float(self.ema_decay)
@@ -157,7 +166,7 @@ class FusedAdam:
         state = {}
         for i, n in enumerate(names):
             o, k, shp = offs[n]
-            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[o:o + k].view(shp).clone() if self.m is not None else None,
+            state[i] = {"step": torch.tensor(float(self.steps.get(n, 0))), "exp_avg": self.m[o:o + k].view(shp).clone() if self.m is not None else None,
                         "exp_avg_sq": self.v[o:o + k].view(shp).clone() if self.v is not None else None}
         grp = dict(self.param_groups[0])
         grp["params"] = list(range(len(names)))
@@ -177,6 +186,7 @@ class FusedAdam:
             o, k = offs[n]
             self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-            self.step_count = int(st["step"])
+            self.steps[n] = int(st["step"])
+            self.step_count = max(self.step_count, self.steps[n])
         g = sd["param_groups"][0]
         self.param_groups[0].update({k: g[k] for k in ("lr", "betas", "eps", "weight_decay") if k in g})

@@ -100,8 +100,9 @@ class DataParallelTokenizer(nn.Module):
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t, src=0, group=process_group)
         if getattr(module, "_engine", None) is None:
-            raise NotImplementedError("this model does not run on the fused engine (bottleneck_type 'fsq'): its gradients are ordinary .grad tensors, "
-                                      "wrap it in torch.nn.parallel.DistributedDataParallel")
+            why = getattr(module, "_composed_why", None)
+            raise NotImplementedError("this model runs on the composed path (no fused engine" + (f": {why}" if why else "") + "): its gradients are "
+                                      "ordinary .grad tensors, wrap it in torch.nn.parallel.DistributedDataParallel")
         module._engine.reducer = GradReducer(process_group, bucket_bytes)
 
     def forward(self, *a, **k):

@@ -27,6 +27,9 @@ from .fsq import FSQ
 from .functional import Linear as LinearFn, PatchEmbed as PatchEmbedFn, _pad64
 from .registry import register
 
+import itertools
+_PACK_UID = itertools.count(1)   # identities of the modules that own packed weight copies (see ResidualAttentionBlock._identity)
+
 
 def get_model_dims(model_size="tiny", head_dim=64, mlp_ratio=4.0):
     """models/model_new/base/utils.py:6-41"""
@@ -241,12 +244,28 @@ class ResidualAttentionBlock(nn.Module):
         self.attn_layer = nn.Sequential(*[Attn(embed_dim, heads) for _ in range(num_layer)])
         self.ffd_layer = nn.Sequential(*[ffd(embed_dim, mlp_ratio) for _ in range(num_layer)])
         self._pack_cache = {}
+        self._vt_epoch = 0
+
+    def _identity(self):
+        """(unique id of THIS module object, invalidation epoch): part of every pack key.  Parameter addresses and `_version`
+        counters alone do not identify a weight: the caching allocator hands a second model of the same geometry the addresses of
+        a deleted first one, and freshly initialised parameters all carry the same version.  The id is re-drawn after
+        copy.deepcopy (the copy's `__dict__` names the original as owner)."""
+        d = self.__dict__
+        if d.get("_vt_uid_owner") != id(self):
+            d["_vt_uid"], d["_vt_uid_owner"] = next(_PACK_UID), id(self)
+        return (d["_vt_uid"], self._vt_epoch)
+
+    def invalidate_packs(self):
+        """call after writing weights through `.data` / under no_grad in a way that does not bump `_version` (`p.data.copy_`)"""
+        self._vt_epoch += 1
+        self._pack_cache.clear()
 
     def _packs(self, i):
         """the layer's bf16 operand copies, re-made only when a weight changed (optimizer step, load_state_dict, .to())"""
         at, ff = self.attn_layer[i], self.ffd_layer[i]
         ws = (at.to_qkv.weight, at.out_proj.weight, ff[1].weight, ff[3].weight)
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        key = (self._identity(),) + tuple((w.data_ptr(), w._version) for w in ws)
         hit = self._pack_cache.get(i)
         if hit is None or hit[0] != key:
             hit = (key, pack_layer_weights(*ws))
@@ -264,7 +283,7 @@ class ResidualAttentionBlock(nn.Module):
                                      at.k_norm.weight, at.k_norm.bias, at.out_proj.weight, ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight)
             return x
         from .functional import GatedStack
-        params, key = [], []
+        params, key = [], [self._identity()]
         for i in range(self.num_layer):
             at, ff = self.attn_layer[i], self.ffd_layer[i]
             params += [at.to_qkv.weight, at.q_norm.weight, at.q_norm.bias, at.k_norm.weight, at.k_norm.bias, at.out_proj.weight, ff[0].weight, ff[0].bias,
