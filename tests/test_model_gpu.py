@@ -321,6 +321,22 @@ def test_config_B_eight_clips_equal_the_sum_of_single_clip_runs():
     assert all(torch.equal(again[n], g8[n]) for n in g8)
 
 
+def test_config_B_parity_also_holds_with_the_five_product_attention_backward():
+    """VT_ATTN_BWD=fused (read once when libvt_hip.so loads, hence a child process) routes the engine's attention backward through
+    vt_attention_bwd_fused -- one kernel, dQ summed across key blocks by the ordered hand-off -- where its chains have slack
+    (22 of the 24 blocks at config B).  The full-size forward + backward parity test above must pass unchanged; its helper also
+    checks the sticky status word (no hand-off timed out)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VT_ATTN_BWD="fused")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_model_gpu.py", "-x", "-q", "-m", "gpu", "-k",
+                        "test_config_B_full_size_forward_backward_matches_oracle or tiny_lastskip"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("name", ["B", "Bp", "C", "D", "E"])
 def test_f256_geometries_size_independent_properties(name):
     """BASELINE configs[1] (B: the headline geometry, pt2 p16, 12+12 blocks, d=24; Bp: the upstream pt4 p8 variant),

@@ -206,7 +206,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const FusedBwdAr
         const int key = k0 + (lane & 31);
         const bool kvalid = key < L;
         const bool ragged_k = key_base + 256 > L;          // workgroup-uniform
-        const int keyrow = wave * 32 + (lane & 31);         // row in the K / dS images
 
         f32x16 dk[2], dv[2];
 #pragma unroll
@@ -516,6 +515,7 @@ extern "C" int vt_attention_bwd_fused(const void* qkv, const void* o_compact, co
         const int64_t n = (int64_t)B * q_begin * (H * 64 / 8);
         hipLaunchKernelGGL(zero_q_rows_kernel2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)dqkv, L, q_begin, (int64_t)3 * H * 64, H * 64);
     }
+    const float c_log2 = 0.125f * 1.44269504088896340736f;
     const int64_t n8 = (int64_t)B * Lq * H * 8;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)o_compact, (const bf16_t*)dO_compact, delta_ws, n8, L, H,
                        q_begin);
@@ -537,7 +537,7 @@ extern "C" int vt_attention_bwd_fused(const void* qkv, const void* o_compact, co
     a.nsl = p.nsl;
     a.nitems = p.nitems;
     a.scale = 0.125f;
-    a.scale_log2e = 0.125f * 1.44269504088896340736f;
+    a.scale_log2e = c_log2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS) != hipSuccess) {

@@ -17,6 +17,9 @@
 
 #include "vt_common.h"
 
+// VT_ATTN_BWD=fused (read once): see attn_bwd() below
+static const bool g_attn_bwd_fused = [] { const char* e = getenv("VT_ATTN_BWD"); return e && strcmp(e, "fused") == 0; }();
+
 namespace {
 
 __global__ void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, int n, float* __restrict__ dst) {
@@ -195,7 +198,7 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
         lb.dxa = a.take((size_t)lb.Mkp * D * 2); lb.dxm = a.take((size_t)lb.Mkp * D * 2); lb.du = a.take((size_t)lb.Mkp * t->D4 * 2);
     }
     t->delta = a.take((size_t)c.B * c.H * t->L * 4);
-    t->attn_ws_bytes = vt_attention_bwd_fused_workspace_bytes(c.B, t->L, c.H, c.D / c.H, 0);   // q_begin = 0 is the largest plan
+    t->attn_ws_bytes = g_attn_bwd_fused ? vt_attention_bwd_fused_workspace_bytes(c.B, t->L, c.H, c.D / c.H, 0) : 0;   // q_begin = 0: the largest plan
     t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
@@ -230,12 +233,14 @@ extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream st
     return VT_OK;
 }
 
-// Attention backward of one block: the five-product kernel with the ordered dQ hand-off where it exists (head_dim 64), the
-// two-kernel form otherwise (the discriminator's head_dim 32) or on request (VT_ATTN_BWD=split, read once: A/B timing in tools/).
-static const bool g_attn_bwd_split = [] { const char* e = getenv("VT_ATTN_BWD"); return e && strcmp(e, "split") == 0; }();
+// Attention backward of one block.  Default: the two-kernel form (dQ kernel + dK/dV kernel, 7 products).  VT_ATTN_BWD=fused (read
+// once) selects the five-product kernel with the ordered dQ hand-off for the blocks where its chains have slack (head_dim 64,
+// at least 3 query slices per key block): correct and bit-reproducible, but measured SLOWER on this chip as hipcc builds it
+// (346 vs 244 us at the step's shape, profiles/r03_attention_bwd_*): kept selectable as the record of the experiment and for A/B.
 static int attn_bwd(vtTokenizer* t, void* ws, const void* qkv, const void* o, const void* dO, const float* lse, int q_begin, void* dqkv, vtStream s) {
     const vtTokenizerConfig& c = t->c;
-    if (t->attn_ws_bytes && !g_attn_bwd_split)
+    const int nsl = (t->L - q_begin + 63) / 64, nkb = (t->L + 255) / 256;
+    if (g_attn_bwd_fused && t->attn_ws_bytes && nsl >= 3 * nkb)
         return vt_attention_bwd_fused(qkv, o, dO, lse, c.B, t->L, c.H, c.D / c.H, q_begin, dqkv, WS(float, t->delta), WS(void, t->attn_ws), t->attn_ws_bytes, s);
     return vt_attention_bwd_rows(qkv, o, dO, lse, c.B, t->L, c.H, c.D / c.H, q_begin, dqkv, WS(float, t->delta), s);
 }
@@ -724,7 +729,7 @@ extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
     }
     t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
     t->delta = a.take((size_t)B * H * L * 4);
-    t->attn_ws_bytes = vt_attention_bwd_fused_workspace_bytes(B, L, H, D / H, 0);   // 0 when head_dim != 64: two-kernel backward
+    t->attn_ws_bytes = g_attn_bwd_fused ? vt_attention_bwd_fused_workspace_bytes(B, L, H, D / H, 0) : 0;   // 0: two-kernel backward
     t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes(t->D4));

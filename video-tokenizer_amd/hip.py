@@ -370,11 +370,10 @@ def attention_fwd(qkv, B, L, H, hd=64, o=None, q_begin=0):
 
 
 def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0, fused=None):
-    """fused=None: the five-product kernel where it exists (head_dim 64), the two-kernel backward otherwise; True / False force one"""
+    """fused=True: the five-product kernel with the ordered dQ hand-off (head_dim 64); default: the two-kernel backward, which is
+    the faster one as measured (DESIGN.md §5 "Attention backward, round 3")"""
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     delta = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32)
-    if fused is None:
-        fused = hd == 64
     if fused:
         n = lib().vt_attention_bwd_fused_workspace_bytes(B, L, H, hd, q_begin)
         if n == 0:
