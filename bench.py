@@ -305,6 +305,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--optimizer", choices=["none", "fused", "torch"], default="none",
                     help="also step Adam(lr 1e-4, betas (0.5,0.9)) inside the timed step: 'fused' = vt_adam_step over flat buffers")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole forward + loss + backward as ONE captured hipGraph (engine.GraphedStep): the small-batch regime "
+                         "(the reference recipe is 1 clip per GPU) is host-bound when enqueued launch by launch")
     ap.add_argument("--gan", action="store_true",
                     help="also time the step with the GAN branch of the trainer (discriminator of cfgs/larp_tokenizer.yaml:113-136, LPIPS off): "
                          "reported under the extra key 'gan_step'; the headline metric is unchanged")
@@ -378,6 +381,18 @@ def main():
         if opt is not None:
             opt.step()
         return loss
+
+    if a.graph:
+        # the whole forward + loss + backward as ONE hipGraph replay (engine.GraphedStep); the optimizer step stays outside
+        assert not multi, "--graph: single process only (the gradient reducer is not captured)"
+        from video_tokenizer_amd.engine import GraphedStep
+        graphed = GraphedStep(model, x, lambda out, xin: (out["pred_frames"] - xin).abs().mean() + 0.1 * out["loss_q"])
+
+        def step():  # noqa: F811
+            loss, _ = graphed(x)
+            if opt is not None:
+                opt.step()
+            return loss
 
     for _ in range(a.warmup):
         step()

@@ -233,6 +233,12 @@ int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t
                   int32_t l2_normalized, float inv_tau, float beta, float codebook_w, uint64_t seed, float* E, float* wnorm,
                   float* zn, float* znorm, int64_t* idx, float* rz, void* rz_pad_bf16, int64_t ldp, float* losses,
                   void* workspace, vtStream stream);
+/* the same with a per-call counter that lives in DEVICE memory (mode 2 only; may be NULL): the sampling noise is hashed from
+ * seed + *seed_counter, so a captured launch draws fresh noise on every replay once the caller increments the counter in the graph */
+int vt_vq_forward_ctr(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
+                      int32_t l2_normalized, float inv_tau, float beta, float codebook_w, uint64_t seed, const uint32_t* seed_counter,
+                      float* E, float* wnorm, float* zn, float* znorm, int64_t* idx, float* rz, void* rz_pad_bf16, int64_t ldp,
+                      float* losses, void* workspace, vtStream stream);
 int vt_vq_backward(const float* g_rz, int64_t ldg, const float* gscal, float beta, float codebook_w, const float* zn,
                    const float* znorm, const float* E, const float* wnorm, const int64_t* idx, int32_t N, int32_t K,
                    int32_t d, int32_t l2_normalized, float* dz_in, void* dz_pad_bf16, int64_t ldp, float* dW,
@@ -433,6 +439,8 @@ int vt_tokenizer_codes_to_encoded(vtTokenizer* tk, const vtTokenizerTensors* par
 int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* tk);
 /* byte offset inside the workspace of the attention backward's sticky status word (see vt_attention_bwd_fused), 0 if unused */
 size_t vt_tokenizer_status_offset(const vtTokenizer* tk);
+/* device-side per-call counter of the stochastic quantizer (see vt_vq_forward_ctr); NULL (the default) = the by-value seed alone */
+int vt_tokenizer_set_seed_counter(vtTokenizer* tk, const uint32_t* seed_counter);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);

@@ -318,6 +318,13 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
         bo = bottleneck_forward(z, p, "bottleneck.", mode, emu, **vq_kw)     # :420
         encoded = bo.pop("output")
         out = {"encoded": encoded, **bo}
+    return {"pred_frames": tokenizer_decode(p, cfg, encoded, emu), **out}
+
+
+def tokenizer_decode(p, cfg, encoded, emu=False):
+    """LARPTokenizer.decode (/root/reference/models/larp_tokenizer.py:456-469): latents (b, Nq, D) -> video, on its own -- the
+    reference's decode() is an ordinary differentiable method (decoder-only fine-tuning on cached latents)"""
+    b = encoded.shape[0]
     lpe = p["decoder_latent_pe"]
     if "decoder_latent_token_type_embed" in p:
         lpe = lpe + p["decoder_latent_token_type_embed"]                # :160-163
@@ -331,8 +338,7 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
     dq = dq.expand(b, -1, -1)
     y = encoder_parallel(zz, dq, p, "decoder.", cfg["decoder_depth"], cfg["decoder_num_heads"], emu)
     y = output_layer(y, p, emu)                                         # :467
-    pred = unpatchify(y, cfg["temporal_patch_size"], cfg["patch_size"], cfg["token_h"]).contiguous()
-    return {"pred_frames": pred, **out}
+    return unpatchify(y, cfg["temporal_patch_size"], cfg["patch_size"], cfg["token_h"]).contiguous()
 
 
 def init_state_dict(cfg, seed=1234, zero_head=False, query_std=0.02):

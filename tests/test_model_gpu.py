@@ -321,6 +321,69 @@ def test_config_B_eight_clips_equal_the_sum_of_single_clip_runs():
     assert all(torch.equal(again[n], g8[n]) for n in g8)
 
 
+def test_encode_and_decode_are_differentiable_on_their_own():
+    """/root/reference/models/larp_tokenizer.py:400-428, 456-487: encode() / decode() / decode_eval() are ordinary differentiable
+    methods.  (1) decoder-only fine-tuning on CACHED latents: z from a no-grad encode (fused engine), decode(z) with the encoder
+    frozen -> gradients of every decoder / head parameter and of z itself against the oracle's decode; (2) encode() alone:
+    gradients of `encoded` and loss_q into the encoder, bottleneck and patch embed against the oracle; (3) the no-grad results of
+    the same calls are the engine's (bit-equal to forward())."""
+    cfg = O.make_cfg("tiny", frame_num=8, input_size=64, bottleneck_token_num=128)
+    model, sd = build(cfg)
+    B = 2
+    x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 91))
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 92))
+    model.train()
+    with torch.no_grad():
+        enc = model.encode(x.cuda())                          # engine path
+        full = model(x.cuda())
+        assert torch.equal(enc["encoded"], full["encoded"]) and torch.equal(enc["bottleneck_rep"], full["bottleneck_rep"])
+        assert torch.equal(model.decode(enc["encoded"]), full["pred_frames"])
+    idx = enc["bottleneck_rep"].cpu()
+
+    # (1) decoder-only fine-tuning on cached latents
+    model.others_requires_grad_(False)
+    z = enc["encoded"].detach().clone().requires_grad_(True)
+    for p_ in model.parameters():
+        p_.grad = None
+    pred = model.decode(z)
+    assert pred.requires_grad
+    (pred * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    dec_names = [n for n, p_ in model.named_parameters() if p_.requires_grad]
+    assert dec_names and all(n.startswith(("decoder.", "final_layer.")) for n in dec_names)
+    p = {k: v.clone().requires_grad_(k in dec_names) for k, v in sd.items()}
+    zr = z.detach().cpu().clone().requires_grad_(True)
+    ref = O.tokenizer_decode(p, cfg, zr, emu=True)
+    (ref * w).sum().backward()
+    assert rel(pred.detach().cpu(), ref.detach()) < 2e-2
+    assert rel(z.grad.cpu(), zr.grad) < 6e-2
+    named = dict(model.named_parameters())
+    bad = [(n, rel(named[n].grad.cpu(), p[n].grad)) for n in dec_names]
+    assert all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:5]
+    assert all(named[n].grad is None for n in named if n not in dec_names)
+    # decode_eval: the same method on fewer query tokens (fewer frames), still differentiable
+    nv_half = model.recon_video_token_num // 2
+    assert model.decode_eval(z, nv_half).requires_grad
+
+    # (2) encode() alone
+    model.others_requires_grad_(True)
+    model.decoder_requires_grad_(False)
+    for p_ in model.parameters():
+        p_.grad = None
+    u = torch.from_numpy(gen.normal((B, cfg["bottleneck_token_num"], 768), 93))
+    out = model.encode(x.cuda())
+    assert out["encoded"].requires_grad and torch.equal(out["bottleneck_rep"].cpu(), idx)
+    ((out["encoded"] * u.cuda()).sum() + 0.7 * out["loss_q"]).backward()
+    torch.cuda.synchronize()
+    enc_names = [n for n, p_ in model.named_parameters() if p_.requires_grad]
+    p = {k: v.clone().requires_grad_(k in enc_names) for k, v in sd.items()}
+    r = O.tokenizer_forward(p, cfg, x, "L", emu=True, force_idx=idx)
+    ((r["encoded"] * u).sum() + 0.7 * r["loss_q"]).backward()
+    assert rel(out["encoded"].detach().cpu(), r["encoded"].detach()) < 2e-2
+    bad = [(n, rel(named[n].grad.cpu(), p[n].grad)) for n in enc_names if p[n].grad is not None]
+    assert len(bad) > 100 and all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:5]
+
+
 def test_config_B_parity_also_holds_with_the_five_product_attention_backward():
     """VT_ATTN_BWD=fused (read once when libvt_hip.so loads, hence a child process) routes the engine's attention backward through
     vt_attention_bwd_fused -- one kernel, dQ summed across key blocks by the ordered hand-off -- where its chains have slack
@@ -540,6 +603,60 @@ def test_forward_is_hipgraph_capturable():
         torch.cuda.synchronize()
     assert torch.equal(out["pred_frames"], eager_new["pred_frames"])
     assert torch.equal(out["bottleneck_rep"], eager_new["bottleneck_rep"])
+
+
+def test_whole_training_step_is_hipgraph_capturable_and_replay_equals_eager():
+    """engine.GraphedStep: forward + loss + backward (~900 launches at full depth) captured once, replayed as one launch.  Replays on
+    new clips must equal the eager step bit for bit -- loss, sampled token ids (stochastic quantizer: the per-call seed word is a
+    device counter incremented inside the graph, so the noise sequence is the eager one), every gradient -- and a FusedAdam step
+    between replays must be seen by the next replay (the weight re-pack is part of the graph)."""
+    from video_tokenizer_amd.engine import GraphedStep
+    from video_tokenizer_amd.optim import FusedAdam
+    cfg = O.make_cfg("tiny", frame_num=8, input_size=64, bottleneck_token_num=128)
+    xs = [torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 300 + i)).cuda() for i in range(4)]
+
+    def loss_fn(out, x):
+        return (out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_q"]
+
+    def fresh():
+        model, _ = build(cfg, stochastic=True)
+        model.train()
+        model.bottleneck.regularizer.set_stochastic_temperature(1.0)      # visibly random draws (tau 0.03 collapses this tiny model)
+        return model, FusedAdam(model, lr=1e-3, betas=(0.5, 0.9))
+
+    # eager reference: three optimizer steps
+    torch.manual_seed(1234)
+    model, opt = fresh()
+    model._engine.seed_counter = 100
+    eager = []
+    for i in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = model(xs[i])
+        loss = loss_fn(out, xs[i])
+        loss.backward()
+        eager.append((loss.detach().clone(), out["bottleneck_rep"].clone(), {n: p_.grad.clone() for n, p_ in model.named_parameters()}))
+        opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(eager[0][1], eager[1][1])
+
+    torch.manual_seed(1234)
+    model2, opt2 = fresh()
+    graphed = GraphedStep(model2, xs[3], loss_fn)                         # captured on some other clip
+    graphed.set_seed_counter(100)
+    for i in range(3):
+        loss, out = graphed(xs[i])
+        torch.cuda.synchronize()
+        assert torch.equal(loss, eager[i][0]), i
+        assert torch.equal(out["bottleneck_rep"], eager[i][1]), i
+        for n, p_ in model2.named_parameters():
+            assert p_.grad is not None and torch.equal(p_.grad, eager[i][2][n]), (i, n)
+        opt2.step()
+    torch.cuda.synchronize()
+    for (n, a), (_, b) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(a, b), n
+    for st in model2._engine.states.values():
+        st.check_status(wait=True)
+    graphed.close()
 
 
 def test_rfvd_evaluator_loop_with_injected_detector():

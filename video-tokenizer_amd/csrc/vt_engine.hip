@@ -87,6 +87,7 @@ struct vtTokenizer {
     size_t hN, meanH, rstdH, yrows;
     // backward scratch
     size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
+    const uint32_t* seed_ctr = nullptr;   // device-side per-call counter of the stochastic VQ (graph replay), see vt_vq_forward_ctr
     size_t attn_ws = 0, attn_ws_bytes = 0;   // five-product attention backward: partial dQ sums + hand-off counters (head_dim 64)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
@@ -216,6 +217,11 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
 extern "C" void vt_tokenizer_destroy(vtTokenizer* t) { delete t; }
 extern "C" size_t vt_tokenizer_workspace_bytes(const vtTokenizer* t) { return t ? t->ws_bytes : 0; }
 extern "C" int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* t) { return t ? 3 + t->c.depth_enc + t->c.depth_dec : 0; }
+extern "C" int vt_tokenizer_set_seed_counter(vtTokenizer* t, const uint32_t* seed_counter) {
+    VT_CHECK_ARG(t, "vt_tokenizer_set_seed_counter: null handle");
+    t->seed_ctr = seed_counter;
+    return VT_OK;
+}
 // byte offset inside the workspace of the attention backward's sticky status word (vt_attention_bwd_fused), 0 if that kernel is not in use
 extern "C" size_t vt_tokenizer_status_offset(const vtTokenizer* t) {
     if (!t || !t->attn_ws_bytes) return 0;
@@ -386,8 +392,8 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
     TRY(vt_gemm_nt(&g, s));
     if (out->projected_z)
         hipLaunchKernelGGL(compact_cols_kernel, dim3((t->Mq * c.d + 255) / 256), dim3(256), 0, (hipStream_t)s, WS(float, t->zproj), (int64_t)64, t->Mq, c.d, out->projected_z);
-    TRY(vt_vq_forward(WS(float, t->zproj), 64, P->codebook, t->Mq, c.K, c.d, c.vq_mode, c.l2_normalized, c.inv_tau, c.beta, c.codebook_w,
-                      seed, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(int64_t, t->vq_idx),
+    TRY(vt_vq_forward_ctr(WS(float, t->zproj), 64, P->codebook, t->Mq, c.K, c.d, c.vq_mode, c.l2_normalized, c.inv_tau, c.beta, c.codebook_w,
+                      seed, t->seed_ctr, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(float, t->vq_zn), WS(float, t->vq_znorm), WS(int64_t, t->vq_idx),
                       WS(float, t->vq_rz), WS(void, t->vq_rzpad), 64, WS(float, t->vq_losses), WS(void, t->vq_ws), s));
     hipStream_t hs = (hipStream_t)s;
     TRY(copy_d2d(out->indices, WS(void, t->vq_idx), (size_t)t->Mq * 8, hs));

@@ -96,7 +96,8 @@ template <int D2, int MODE>
 __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ zn, const float* __restrict__ zz,
                                                          const float* __restrict__ ET, const float* __restrict__ ee, int N, int K,
                                                          int Kp, float inv_tau, unsigned seed_lo, unsigned seed_hi,
-                                                         int chunks_per_split, float* __restrict__ pscore, int* __restrict__ pidx) {
+                                                         int chunks_per_split, float* __restrict__ pscore, int* __restrict__ pidx,
+                                                         const unsigned* __restrict__ seed_ctr) {
     constexpr int D = 2 * D2;
     constexpr int UNITS = (D * (CHUNK / 4) + 255) / 256;  // float4 staging units per thread
     __shared__ __attribute__((aligned(16))) float lds_e[2][D][CHUNK];
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict_
     const int tl = lane & 31, h = lane >> 5;
     const int tok_base = blockIdx.x * 256 + wave * 64;
     const int split = blockIdx.y;
+    // per-call counter kept on the DEVICE (a replayed hipGraph cannot change a by-value seed): added to the low seed word
+    if (MODE == 2 && seed_ctr) seed_lo += *seed_ctr;
     const int chunk_begin = split * chunks_per_split;
     const int nchunks_total = Kp / CHUNK;
     const int chunk_end = chunk_begin + chunks_per_split < nchunks_total ? chunk_begin + chunks_per_split : nchunks_total;
@@ -416,10 +419,10 @@ extern "C" size_t vt_vq_workspace_bytes(int32_t N, int32_t K, int32_t d) {
     return (f > bwd ? f : bwd) * 4;
 }
 
-extern "C" int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
-                             int32_t l2_normalized, float inv_tau, float beta, float codebook_w, uint64_t seed, float* E, float* wnorm,
-                             float* zn, float* znorm, int64_t* idx, float* rz, void* rz_pad_bf16, int64_t ldp, float* losses,
-                             void* workspace, vtStream stream) {
+extern "C" int vt_vq_forward_ctr(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
+                                 int32_t l2_normalized, float inv_tau, float beta, float codebook_w, uint64_t seed, const uint32_t* seed_counter,
+                                 float* E, float* wnorm, float* zn, float* znorm, int64_t* idx, float* rz, void* rz_pad_bf16, int64_t ldp,
+                                 float* losses, void* workspace, vtStream stream) {
     VT_CHECK_ARG(z_in && codebook && E && wnorm && zn && znorm && idx && rz && losses && workspace, "vt_vq_forward: null pointer");
     VT_CHECK_ARG(N > 0 && K > 0 && (d == 8 || d == 16 || d == 24 || d == 32), "vt_vq_forward: d=%d must be 8,16,24 or 32", d);
     VT_CHECK_ARG(mode >= 0 && mode <= 2, "vt_vq_forward: mode must be 0 (l2 argmin), 1 (cos argmax) or 2 (cos sample)");
@@ -441,7 +444,7 @@ extern "C" int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebo
     hipLaunchKernelGGL(vq_prep_tokens_kernel, dim3((N + 255) / 256), dim3(256), 0, s, z_in, ldz, N, d, l2_normalized, zn, znorm, zz);
     const dim3 grid(nblk, S);
     const unsigned slo = (unsigned)(seed & 0xffffffffu), shi = (unsigned)(seed >> 32);
-#define VQ_SEARCH(D2, M) hipLaunchKernelGGL((vq_search_kernel<D2, M>), grid, dim3(256), 0, s, zn, zz, ET, ee, N, K, Kp, inv_tau, slo, shi, cps, pscore, pidx)
+#define VQ_SEARCH(D2, M) hipLaunchKernelGGL((vq_search_kernel<D2, M>), grid, dim3(256), 0, s, zn, zz, ET, ee, N, K, Kp, inv_tau, slo, shi, cps, pscore, pidx, seed_counter)
 #define VQ_SEARCH_D(M)                                   \
     switch (d) {                                         \
         case 8: VQ_SEARCH(4, M); break;                  \
@@ -460,6 +463,14 @@ extern "C" int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebo
     hipLaunchKernelGGL(vq_loss_kernel, dim3(1), dim3(64), 0, s, partial, nblk, 1.0f / ((float)N * (float)d), beta, codebook_w, losses);
     VT_CHECK_LAUNCH("vt_vq_forward/finalize");
     return VT_OK;
+}
+
+extern "C" int vt_vq_forward(const float* z_in, int64_t ldz, const float* codebook, int32_t N, int32_t K, int32_t d, int32_t mode,
+                             int32_t l2_normalized, float inv_tau, float beta, float codebook_w, uint64_t seed, float* E, float* wnorm,
+                             float* zn, float* znorm, int64_t* idx, float* rz, void* rz_pad_bf16, int64_t ldp, float* losses,
+                             void* workspace, vtStream stream) {
+    return vt_vq_forward_ctr(z_in, ldz, codebook, N, K, d, mode, l2_normalized, inv_tau, beta, codebook_w, seed, nullptr, E, wnorm, zn, znorm, idx, rz,
+                             rz_pad_bf16, ldp, losses, workspace, stream);
 }
 
 extern "C" int vt_vq_gather(const float* E, const int64_t* idx, int32_t N, int32_t K, int32_t d, float* out, void* out_pad_bf16,

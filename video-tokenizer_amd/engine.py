@@ -148,6 +148,7 @@ class TokenizerEngine:
         self.segments = None  # stage -> (lo, hi) element range of the flat gradient buffer
         self.reducer = None   # set by parallel.DataParallelTokenizer
         self.seed_counter = 0
+        self.graph_mode = False   # GraphedStep: weights are re-packed inside the captured step, the VQ seed counter lives on the device
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(model) (the reference trainer builds its EMA model that way, base_trainer.py:396-405) must not
@@ -229,13 +230,15 @@ class TokenizerEngine:
 
     def ensure_packed(self, st, pstruct):
         v = self.params_version()
-        if st.packed_version != v:
+        if st.packed_version != v or self.graph_mode:      # under capture the pack is part of the graph: weights change every replay
             hip.check(hip.lib().vt_tokenizer_pack(st.handle, ctypes.byref(pstruct.struct), hip.ptr(st.ws), hip.stream()), "vt_tokenizer_pack")
             st.packed_version = v
 
     def next_seed(self):
-        self.seed_counter += 1
         base = int(torch.initial_seed()) & 0xFFFFFFFF
+        if self.graph_mode:                 # the per-call word is added on the device (vt_vq_forward_ctr): same sequence as eager
+            return base << 32
+        self.seed_counter += 1
         return (base << 32) | (self.seed_counter & 0xFFFFFFFF)
 
 
@@ -313,7 +316,9 @@ class TokenizerFunction(torch.autograd.Function):
             raise hip.HipError("LARPTokenizer.backward: the engine workspace was overwritten by a later forward with the same "
                                "geometry; run backward before the next forward")
         dev = st.ws.device
-        st.check_status()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            st.check_status()
         engine.ensure_flat_grad(dev)
         if d_pred is None:
             d_pred = torch.zeros(ctx.x_shape, device=dev, dtype=torch.float32)
@@ -344,7 +349,8 @@ class TokenizerFunction(torch.autograd.Function):
                 done += 1
         if red is not None:
             red.finish()
-        st.post_status()
+        if not capturing:
+            st.post_status()
         grads = []
         # autograd wants gradients in the order the parameters were passed to apply().  NOTE for callers: except in the aliased
         # case these are views of ONE reused buffer -- the next backward of this model overwrites them.
@@ -365,3 +371,76 @@ def apply(engine, x):
     order = _flat_order(engine.model)
     engine.apply_names = [n for n, _, _ in order]
     return TokenizerFunction.apply(engine, x, *[p for _, p, _ in order])
+
+
+class GraphedStep:
+    """The whole forward + loss + backward of a fixed geometry captured ONCE as a hipGraph (torch.cuda.CUDAGraph) and replayed.
+
+    Why: at the reference's own recipe -- global batch 8 on 8 GPUs = ONE clip per GPU (scripts/train_larp_tokenizer_reproduce.sh:8,
+    trainers/base_trainer.py:316) -- the GPU needs 3-4 ms per step and the host ~5 ms to enqueue its ~900 launches: the step is
+    host-bound.  A replay costs one launch.  What makes the step capturable: the engine never allocates or synchronises; the weight
+    re-pack runs inside the graph; the stochastic quantizer's per-call seed word is a DEVICE counter incremented in the graph
+    (vt_vq_forward_ctr), giving the same noise sequence as eager calls; gradients land in the engine's flat buffer, whose views
+    the parameters' .grad keep pointing at.  The optimizer step stays outside (FusedAdam.step() is 4-5 launches).
+
+        graphed = GraphedStep(model, x_example, loss_fn)          # loss_fn(out_dict, x) -> scalar tensor
+        for x in loader:
+            loss, out = graphed(x)                                # replay; outputs are static tensors, valid until the next replay
+            opt.step()                                            # do NOT set grads to None in between (zero_grad(set_to_none=False) or nothing)
+
+    Single process only: a data-parallel reducer (parallel.DataParallelTokenizer) is not captured."""
+
+    def __init__(self, model, x, loss_fn, warmup=2):
+        eng = model._engine
+        if eng is None:
+            raise NotImplementedError("GraphedStep needs the fused engine (this model runs on the composed path)")
+        if eng.reducer is not None:
+            raise NotImplementedError("GraphedStep: the data-parallel gradient reducer is not captured; use the eager step under DataParallelTokenizer")
+        self.model, self.engine, self.loss_fn = model, eng, loss_fn
+        from .optim import flatten_parameters
+        flatten_parameters(model)       # parameter ADDRESSES are baked into the graph: move them into the flat buffer FusedAdam uses now, not later
+        self.x = x.detach().clone().contiguous().float()
+        B, _, T, S, _ = self.x.shape
+        self.state = eng.state_for(B, T, S, self.x.device)
+        self.ctr = torch.full((1,), eng.seed_counter & 0x7FFFFFFF, dtype=torch.int32, device=self.x.device)
+        hip.check(hip.lib().vt_tokenizer_set_seed_counter(self.state.handle, hip.ptr(self.ctr)), "vt_tokenizer_set_seed_counter")
+        eng.graph_mode = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):               # warm-up on a side stream: kernel attributes, workspaces, autograd buffers
+            for _ in range(max(1, warmup)):
+                self._step()
+                eng.seed_counter += 1
+        torch.cuda.current_stream().wait_stream(side)
+        for p in model.parameters():
+            p.grad = None                           # capture with empty .grad: AccumulateGrad adopts the flat-buffer views, no add kernels
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.out = self._step()
+        self.state.check_status(wait=False)
+
+    def _step(self):
+        self.ctr.add_(1)
+        out = self.model(self.x)
+        loss = self.loss_fn(out, self.x)
+        loss.backward()
+        return loss, out
+
+    def set_seed_counter(self, k):
+        """the next replay draws the quantizer noise of eager call number k + 1"""
+        self.ctr.fill_(int(k) & 0x7FFFFFFF)
+        self.engine.seed_counter = int(k)
+
+    def __call__(self, x):
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        eng = self.engine
+        eng.seed_counter += 1
+        for name, p in self.model.named_parameters():          # a caller that dropped .grad gets the (re-written) views back
+            if p.grad is None and p.requires_grad and name in eng.grad_views:
+                p.grad = eng.grad_views[name].view(p.shape)
+        return self.loss, self.out
+
+    def close(self):
+        hip.check(hip.lib().vt_tokenizer_set_seed_counter(self.state.handle, None), "vt_tokenizer_set_seed_counter")
+        self.engine.graph_mode = False

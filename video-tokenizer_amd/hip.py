@@ -72,6 +72,8 @@ SIGNATURES = {
     "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "vt_vq_forward_ctr": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vt_vq_backward": (c_i32, [c_vp, c_i64, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "vt_vq_prep_codebook": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
@@ -171,6 +173,7 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_codes_to_encoded": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_num_backward_stages": (c_i32, [c_vp]),
     "vt_tokenizer_status_offset": (c_sz, [c_vp]),
+    "vt_tokenizer_set_seed_counter": (c_i32, [c_vp, c_vp]),
     "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, ctypes.POINTER(c_i32), c_vp]),
 }
 

@@ -397,22 +397,17 @@ class LARPTokenizer(nn.Module):
         T = nv // self.decoder_token_h ** 2 * self.decoder_temporal_patch_size
         return Unpatchify.apply(rows.reshape(B * nv, -1), (B, self.out_channels, T, self.input_size, self.decoder_temporal_patch_size, self.decoder_patch_size))
 
-    def _warn_if_graph_expected(self, who, *tensors):
-        """encode / decode on their own are forward-only here (the reference's are ordinary differentiable methods,
-        larp_tokenizer.py:400-487): only forward(data) carries a backward.  Say so once instead of silently returning
-        graph-less tensors to a caller that is recording a graph."""
-        if torch.is_grad_enabled() and not getattr(self, "_warned_nograd", False) and (
-                any(t.requires_grad for t in tensors if torch.is_tensor(t)) or (self.training and any(p.requires_grad for p in self.parameters()))):
-            import warnings
-            self._warned_nograd = True
-            warnings.warn(f"LARPTokenizer.{who}: forward-only in this build (no autograd graph is recorded); back-propagate through "
-                          "model(data) instead.  Wrap the call in torch.no_grad() to silence this.", stacklevel=3)
+    def _graph_expected(self, params, *tensors):
+        """True when the caller is recording an autograd graph that this call belongs to: grad mode on and an input or one of
+        the parameters the call uses requires a gradient"""
+        return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if torch.is_tensor(t)) or any(p.requires_grad for p in params))
 
     def encode(self, x):
-        """larp_tokenizer.py:400-428 (vq / sq branches: forward only; fsq: differentiable)."""
-        if self._composed:
+        """larp_tokenizer.py:400-428: an ordinary differentiable method in the reference.  Forward-only calls (no_grad, eval
+        pipelines) run the fused engine; when a graph is being recorded the same kernels run through the sub-modules' autograd
+        functions (the composed path), so `encode(x)['encoded']`, the losses and every encoder / bottleneck parameter get gradients."""
+        if self._composed or self._graph_expected(self.others_parameters(), x):
             return self._composed_encode(x)
-        self._warn_if_graph_expected("encode", x)
         with torch.no_grad():
             return self._encode(x)
 
@@ -429,10 +424,11 @@ class LARPTokenizer(nn.Module):
         return out
 
     def decode(self, z, num_x_tokens=None):
-        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video.  Forward only (fsq: differentiable)."""
-        if self._composed:
+        """larp_tokenizer.py:456-469 / :471-482 (decode_eval): z (b, Nq, D) -> video.  Differentiable like the reference's (decoder-only
+        fine-tuning on cached latents, gradients w.r.t. z): with a graph being recorded the composed path runs, otherwise the engine."""
+        extra = [self.decoder_patch_query_token_type_embed] if self.use_decoder_patch_query_token_type_embed else []
+        if self._composed or self._graph_expected(itertools.chain(self.decoder_parameters(), extra), z):
             return self._composed_decode(z, num_x_tokens)
-        self._warn_if_graph_expected("decode", z)
         with torch.no_grad():
             return self._decode(z, num_x_tokens)
 
