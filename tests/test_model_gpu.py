@@ -381,7 +381,7 @@ def test_encode_and_decode_are_differentiable_on_their_own():
     ((r["encoded"] * u).sum() + 0.7 * r["loss_q"]).backward()
     assert rel(out["encoded"].detach().cpu(), r["encoded"].detach()) < 2e-2
     bad = [(n, rel(named[n].grad.cpu(), p[n].grad)) for n in enc_names if p[n].grad is not None]
-    assert len(bad) > 100 and all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:5]
+    assert len(bad) >= 20 and all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:5]
 
 
 def test_config_B_parity_also_holds_with_the_five_product_attention_backward():
