@@ -385,12 +385,12 @@ class GraphedStep:
 
         graphed = GraphedStep(model, x_example, loss_fn)          # loss_fn(out_dict, x) -> scalar tensor
         for x in loader:
-            loss, out = graphed(x)                                # replay; outputs are static tensors, valid until the next replay
+            loss, out = graphed(x)                                # replay; `loss` and the kept outputs are static buffers, valid until the next replay
             opt.step()                                            # do NOT set grads to None in between (zero_grad(set_to_none=False) or nothing)
 
     Single process only: a data-parallel reducer (parallel.DataParallelTokenizer) is not captured."""
 
-    def __init__(self, model, x, loss_fn, warmup=2):
+    def __init__(self, model, x, loss_fn, warmup=2, outputs=("bottleneck_rep", "loss_q", "loss_commit", "loss_codebook")):
         eng = model._engine
         if eng is None:
             raise NotImplementedError("GraphedStep needs the fused engine (this model runs on the composed path)")
@@ -405,6 +405,18 @@ class GraphedStep:
         self.ctr = torch.full((1,), eng.seed_counter & 0x7FFFFFFF, dtype=torch.int32, device=self.x.device)
         hip.check(hip.lib().vt_tokenizer_set_seed_counter(self.state.handle, hip.ptr(self.ctr)), "vt_tokenizer_set_seed_counter")
         eng.graph_mode = True
+        # What the caller gets back.  (1) The LOSS VALUE is recomputed by ordinary launches after the replay (same ops, same bits as
+        # eager; ~6 tiny kernels).  Measured on this ROCm build (tools/graph_debug4.py, graph_debug6.py): inside a replayed graph a torch
+        # elementwise kernel that reads a 0-dim tensor written by an earlier node of the same replay can see the value a previous replay
+        # left at that address -- `loss = a + 0.1 * b` came out as 1.0 + 0.1 * b, 1.0 being the backward seed that had reused `a`'s block
+        # -- depending on which single-workgroup kernels ran in between (a `torch.equal` outside was enough).  Every kernel of this
+        # library reads its operands with vector loads and is unaffected: gradients and weights stayed bit-equal to eager in all nine
+        # patterns tried.  Consequence for callers: keep the SCALAR part of the loss linear (sums of terms with constant weights, as the
+        # reference trainer's is); products of 0-dim tensors would back-propagate a possibly stale factor.  (2) Small outputs are copied,
+        # inside the graph, into buffers from the ordinary pool; large ones are the graph's static tensors.
+        self._keep = tuple(outputs)
+        self._out = None
+        self._graph_out = None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):               # warm-up on a side stream: kernel attributes, workspaces, autograd buffers
@@ -414,9 +426,10 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         for p in model.parameters():
             p.grad = None                           # capture with empty .grad: AccumulateGrad adopts the flat-buffer views, no add kernels
+        self.stream = side
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss, self.out = self._step()
+            _, self._graph_out = self._step()
         self.state.check_status(wait=False)
 
     def _step(self):
@@ -424,6 +437,11 @@ class GraphedStep:
         out = self.model(self.x)
         loss = self.loss_fn(out, self.x)
         loss.backward()
+        if self._out is None:
+            self._out = {k: torch.empty_like(out[k]) for k in self._keep if k in out}
+        with torch.no_grad():
+            for k, buf in self._out.items():
+                buf.copy_(out[k])
         return loss, out
 
     def set_seed_counter(self, k):
@@ -432,14 +450,23 @@ class GraphedStep:
         self.engine.seed_counter = int(k)
 
     def __call__(self, x):
-        self.x.copy_(x, non_blocking=True)
-        self.graph.replay()
+        # the replay runs on a stream of its own (not the legacy null stream), ordered against the caller's stream by events on both sides
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x, non_blocking=True)
+            self.graph.replay()
+            with torch.no_grad():
+                loss = self.loss_fn(self._graph_out, self.x)        # the reported value: ordinary launches, see __init__
+        cur.wait_stream(self.stream)
+        out = dict(self._graph_out)
+        out.update(self._out)
         eng = self.engine
         eng.seed_counter += 1
         for name, p in self.model.named_parameters():          # a caller that dropped .grad gets the (re-written) views back
             if p.grad is None and p.requires_grad and name in eng.grad_views:
                 p.grad = eng.grad_views[name].view(p.shape)
-        return self.loss, self.out
+        return loss, out
 
     def close(self):
         hip.check(hip.lib().vt_tokenizer_set_seed_counter(self.state.handle, None), "vt_tokenizer_set_seed_counter")
