@@ -100,7 +100,7 @@ def time_dominant_kernel(B, c, reps=20):
 def measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from PMC counters (cannot be collected inside this process):
     the rocprofv3 passes of tools/pmc_traffic.sh, committed under profiles/."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None
     with open(path) as f:

@@ -406,7 +406,16 @@ class LARP_AR(nn.Module):
             b.attention.kv_cache = None
 
     def forward(self, idx, cond_idx, input_pos=None, targets=None, mask=None, valid=None):
-        """larp_ar.py:346-409"""
+        """larp_ar.py:346-409.  Cached inference (`input_pos` given): positions must lie in [0, max_seq_len of setup_caches).  A HOST
+        `input_pos` is checked here and raises like the reference's index_put would; a DEVICE `input_pos` (the generation loop keeps
+        it on the GPU so that a decode step is graph-capturable) cannot be checked without a synchronisation: the decode kernel then
+        CLAMPS an out-of-range position to the last cache row instead of faulting -- generate() never produces one."""
+        if input_pos is not None and torch.is_tensor(input_pos) and not input_pos.is_cuda and input_pos.numel():
+            lmax = self.layers[0].attention.kv_cache.k_cache.shape[2] if getattr(self.layers[0].attention, "kv_cache", None) is not None else None
+            lo, hi = int(input_pos.min()), int(input_pos.max())
+            if lo < 0 or (lmax is not None and hi >= lmax):
+                raise IndexError(f"LARP_AR.forward: input_pos in [{lo}, {hi}] is outside the KV cache (0 .. {lmax - 1 if lmax else '?'})")
+            input_pos = input_pos.to(self.tok_embeddings.weight.device)
         if mask is not None:
             raise NotImplementedError("an explicit attention mask is not built: training is causal, cached inference uses positions")
         cached = False

@@ -97,7 +97,12 @@ def rope_positions_unify(cond_tokens, in_tokens, grid):
     cannot broadcast the two and raises -- as shipped none of the autoencoder_first_token_* models can run a forward pass.
     This build keeps get_freqs_multi's construction (pair i is offset by the maximum coordinate of pair i-1, rope.py:134-136) and
     takes the rows of the tokens that are actually present: the latents of pair 0 (the first-frame GRID rows have no token in the
-    decoder), then pair 1 = [in_tokens latents | grid] with the model's own in_tokens."""
+    decoder), then pair 1 = [in_tokens latents | grid] with the model's own in_tokens.
+
+    PARITY UNPINNED: no reference output exists for these models (their forward raises as shipped), so this repair is this build's
+    own reading of the intent; a checkpoint trained with a differently repaired reference would need its own positions --
+    `positions=` of Decoder_unify accepts an override ([rows, 3] integer coordinates) for that case.
+    """
     p0 = rope_positions(cond_tokens, [1, grid[1], grid[2]])
     p1 = rope_positions(in_tokens, grid) + p0.max()
     return np.concatenate([p0[:cond_tokens], p1], axis=0)
@@ -380,7 +385,8 @@ class DecoderUnify(nn.Module, _RopeMixin):
     last grid_size rows -> ConvTranspose3d.  Two shipped quirks are NOT reproduced (see rope_positions_unify and DESIGN.md): the
     hard-coded 2560-row rotary table that makes the reference's forward raise, and the debug print in forward (:776)."""
 
-    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=5, out_channels=3, in_tokens=1024, cond_tokens=256, out_grid=(16, 128, 128)):
+    def __init__(self, model_size="tiny", patch_size=(4, 8, 8), in_channels=5, out_channels=3, in_tokens=1024, cond_tokens=256, out_grid=(16, 128, 128),
+                 positions=None):
         super().__init__()
         self.patch_size, self.token_size, self.in_channels = tuple(patch_size), in_channels, out_channels
         self.in_tokens, self.cond_tokens, self.out_grid = in_tokens, cond_tokens, tuple(out_grid)
@@ -392,7 +398,8 @@ class DecoderUnify(nn.Module, _RopeMixin):
         if self.cond_tokens > 0:
             self.proj_cond = nn.Linear(self.token_size, self.width, bias=True)
         self.mask_token = nn.Parameter(self.width ** -0.5 * torch.randn(1, 1, 1))
-        self.freqs = rope_tables_from_positions(rope_positions_unify(cond_tokens, in_tokens, self.grid), head_dim=self.width // self.heads)
+        self.freqs = rope_tables_from_positions(rope_positions_unify(cond_tokens, in_tokens, self.grid) if positions is None else positions,
+                                                head_dim=self.width // self.heads)   # `positions`: see rope_positions_unify (parity unpinned)
         self._freqs_dev = None
         self.model_layers = ResidualAttentionBlock(self.width, self.heads, mlp_ratio, self.num_layers)
         self.proj_out = nn.ConvTranspose3d(self.width, out_channels, kernel_size=self.patch_size, stride=self.patch_size, bias=True)
