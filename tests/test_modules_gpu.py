@@ -220,8 +220,30 @@ def test_lpips_disc_loss_generator_and_discriminator_branches():
     bad = dict(spec["args"], r1_gp_weight=1.0)
     with pytest.raises(NotImplementedError):
         vt.make({"name": "lpips_disc_loss", "args": bad})
-    with pytest.raises(NotImplementedError):
-        vt.make({"name": "lpips_disc_loss", "args": dict(spec["args"], perceptual_weight=1.0)})
+    # the SHIPPED spec (cfgs/larp_tokenizer.yaml:120: perceptual_weight 1.0, perceptual_loss 'lpips') constructs and runs: lpips.py is a
+    # torch-ops VGG-16 metric with the lpips package's state-dict layout (parity unpinned: the package is not importable here; without
+    # user-supplied weights it warns once and runs on a seeded random init)
+    import warnings
+    lp = vt.make({"name": "lpips_disc_loss", "args": dict(spec["args"], perceptual_weight=1.0)}).cuda()
+    keys = set(lp.state_dict().keys())
+    assert {"perceptual_loss.scaling_layer.shift", "perceptual_loss.net.slice1.0.weight", "perceptual_loss.net.slice5.28.bias",
+            "perceptual_loss.lin0.model.1.weight", "perceptual_loss.lins.4.model.1.weight"} <= keys
+    assert not any(q.requires_grad for q in lp.perceptual_loss.parameters()) and not lp.perceptual_loss.training
+    lp.set_training_mode(True)
+    assert not lp.perceptual_loss.training and lp.discriminator.training          # the frozen metric stays in eval
+    fg2 = fake.detach().clone().cuda().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss_p, info_p, _ = lp(real.cuda(), fg2, global_step=10, for_discriminator=False)
+        same, info_s, _ = lp(real.cuda(), real.cuda(), global_step=10, for_discriminator=False)
+    loss_p.backward()
+    assert torch.isfinite(loss_p) and float(info_p["perceptual_loss"]) > 0 and float(info_s["perceptual_loss"]) == 0.0   # lpips(x, x) = 0
+    assert fg2.grad is not None and torch.isfinite(fg2.grad).all() and float(fg2.grad.abs().max()) > 0
+    sd_l = {k[len("perceptual_loss."):]: v for k, v in lp.state_dict().items() if k.startswith("perceptual_loss.")}
+    from video_tokenizer_amd.lpips import LPIPS
+    again = LPIPS()
+    again.load_state_dict(sd_l, strict=True)                                       # the package's key layout round-trips
+    assert again.weights_loaded
 
 
 def test_discriminator_at_the_shipped_size():
