@@ -237,7 +237,7 @@ def test_lpips_disc_loss_generator_and_discriminator_branches():
         loss_p, info_p, _ = lp(real.cuda(), fg2, global_step=10, for_discriminator=False)
         same, info_s, _ = lp(real.cuda(), real.cuda(), global_step=10, for_discriminator=False)
     loss_p.backward()
-    assert torch.isfinite(loss_p) and float(info_p["perceptual_loss"]) > 0 and float(info_s["perceptual_loss"]) == 0.0   # lpips(x, x) = 0
+    assert torch.isfinite(loss_p) and float(info_p["perceptual_loss"]) > 1e-4 and abs(float(info_s["perceptual_loss"])) < 1e-8   # lpips(x, x) = 0 (to the convolutions' run-to-run rounding)
     assert fg2.grad is not None and torch.isfinite(fg2.grad).all() and float(fg2.grad.abs().max()) > 0
     sd_l = {k[len("perceptual_loss."):]: v for k, v in lp.state_dict().items() if k.startswith("perceptual_loss.")}
     from video_tokenizer_amd.lpips import LPIPS
