@@ -270,6 +270,32 @@ def test_patchify_unpatchify(hip, pt, p, T, S):
     assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 768, 3072), (1536, 2304, 768), (3072, 768, 768), (1536, 768, 256), (200, 392, 448), (128, 128, 64)])
+def test_gemm_nt_deep_ring_is_bit_identical_to_the_two_stage_kernel(hip, M, N, K):
+    """vtGemmNT.tile = 16: the 128x128 kernel behind a 4-deep LDS ring with counted waits (picked automatically when the launch has at
+    most one workgroup per CU: one or two clips per GPU).  Same MFMA order as the 2-deep ring (tile 1) => every epilogue's output must be
+    bit-identical, for K from 1 to 48 K-tiles, ragged M / N, and the automatic choice must be one of the two."""
+    A = bf(_rand((M, K), 700 + K))
+    B = bf(_rand((N, K), 701 + N))
+    bias = torch.from_numpy(_rand((N,), 702)).cuda()
+    res = torch.from_numpy(_rand((M, N), 703)).cuda()
+    u = bf(_rand((M, N), 704)).cuda()
+    a, b = A.cuda(), B.cuda()
+    for kw in (dict(epi=hip.EPI_BF16, bias=bias), dict(epi=hip.EPI_F32, bias=bias, residual=res, round_bf16=True), dict(epi=hip.EPI_BF16_GELU, bias=bias),
+               dict(epi=hip.EPI_BF16_DGELU, aux=u)):
+        two = hip.gemm_nt(a, b, tile=1, **kw)
+        deep = hip.gemm_nt(a, b, tile=16, **kw)
+        auto = hip.gemm_nt(a, b, tile=0, **kw)
+        torch.cuda.synchronize()
+        for x, y, z in zip(*(t if isinstance(t, tuple) else (t,) for t in (two, deep, auto))):
+            assert torch.equal(x, y), kw["epi"]
+            if N >= 192 and M >= 192 and kw["epi"] != hip.EPI_BF16_DGELU:
+                assert torch.equal(x, z), kw["epi"]       # 192-tile kernels accumulate K in the same order too
+    ref = (A.float() @ B.float().t() + bias.cpu()).to(torch.bfloat16)
+    got = hip.gemm_nt(a, b, tile=16, epi=hip.EPI_BF16, bias=bias).cpu()
+    assert (got.float() - ref.float()).abs().max() <= 2e-2 * max(1.0, ref.float().abs().max().item())
+
+
 # -------------------------------------------------------------------------------------- attention
 def _attn_ref(qkv, B, L, H, hd=64):
     q, k, v = qkv.reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)

@@ -47,7 +47,12 @@ __device__ __forceinline__ bf16x8 frag_nt(const char* lds, int row, int lchunk) 
     return *(const bf16x8*)(lds + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int EPI>
+// NST = 2: the ring described in the header (two workgroups per CU: one's loads land under the other's MFMAs).
+// NST = 4: the same tile, same MFMA order (bit-identical results) behind a 4-deep ring filled by inline-asm LDS-DMA, counted
+//          s_waitcnt vmcnt(16) + raw s_barrier per K-tile (two K-tiles stay in flight across the barrier) -- for launches with at
+//          most one workgroup per CU (M = 1536 or 3072: one or two clips per GPU), where nothing else hides the ~1 us a K-tile's
+//          loads take and the 2-deep ring ran one K-tile per load latency (fc2 forward at one clip: 48 K-tiles = 50 us on 72 CUs).
+template <int EPI, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const vtGemmNT& p = a.p;
@@ -73,18 +78,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
     const int nt = p.K / BK;
     // LDS: [buffer 0: A | B][buffer 1: A | B]
 
-    stage_nt(A, p.lda, m0, p.M, 0, smem, tid, wave);
-    stage_nt(B, p.ldb, n0, p.N, 0, smem + TILE_B, tid, wave);
-    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-
     const int fr = lane & 15, fq = lane >> 4;
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) {
-            stage_nt(A, p.lda, m0, p.M, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_B, tid, wave);
-            stage_nt(B, p.ldb, n0, p.N, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_B + TILE_B, tid, wave);
-        }
-        const char* la = smem + cur * 2 * TILE_B;
+    // one K-tile of MFMAs out of the stage at `la` (A image) / `la + TILE_B` (B image)
+    auto multiply = [&](const char* la) {
         const char* lb = la + TILE_B;
         bf16x8 af[2][4], bfv[2][4];  // all 16 fragment reads first, MFMAs behind counted lgkmcnt waits
 #pragma unroll
@@ -103,7 +99,61 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+    };
+    if constexpr (NST == 2) {
+        stage_nt(A, p.lda, m0, p.M, 0, smem, tid, wave);
+        stage_nt(B, p.ldb, n0, p.N, 0, smem + TILE_B, tid, wave);
+        __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt) {
+                stage_nt(A, p.lda, m0, p.M, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_B, tid, wave);
+                stage_nt(B, p.ldb, n0, p.N, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_B + TILE_B, tid, wave);
+            }
+            multiply(smem + cur * 2 * TILE_B);
+            __syncthreads();
+        }
+    } else {
+        constexpr int STAGE = 2 * TILE_B;
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+        unsigned offa[4], offb[4];      // loop-invariant lane offsets (bytes) inside A / B; the K-tile moves the scalar base
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot >> 3;
+            const int lc = (slot & 7) ^ ((row >> 1) & 7);
+            int ra = m0 + row, rb = n0 + row;
+            ra = ra < p.M ? ra : p.M - 1;
+            rb = rb < p.N ? rb : p.N - 1;
+            offa[i] = (unsigned)(((int64_t)ra * p.lda + lc * 8) * 2);
+            offb[i] = (unsigned)(((int64_t)rb * p.ldb + lc * 8) * 2);
+        }
+        auto issue = [&](int t, int slot) {
+            const bf16_t* ak = A + (int64_t)t * BK;
+            const bf16_t* bk = B + (int64_t)t * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16_sv(ak, offa[i], sbase + slot * STAGE + (i * 256 + wave * 64) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16_sv(bk, offb[i], sbase + slot * STAGE + TILE_B + (i * 256 + wave * 64) * 16);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_)
+            if (s_ < nt) issue(s_, s_);
+        if (nt >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 2)) : "memory");   // K-tile 0 landed, the next NST-2 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot = 0, fill = NST - 1;                       // ring positions of the K-tile being multiplied / being filled
+        for (int t = 0; t < nt; ++t) {
+            const bool more = t + NST - 1 < nt;
+            if (more) issue(t + NST - 1, fill);            // the slot read in iteration t-1: every wave is past that barrier
+            multiply(smem + slot * STAGE);
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 2)) : "memory");   // K-tile t+1 landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == NST ? 0 : slot + 1;
+            fill = fill + 1 == NST ? 0 : fill + 1;
+        }
     }
 
     // ---- epilogue: acc[i][j][r] = C[m0 + wr*64 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
@@ -393,7 +443,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
     const int g_gemm_variant = p.tile;   // per call (vtGemmNT.tile); the library holds no tile setting of its own
-    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 15, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4 timing ablations)", g_gemm_variant);
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 16, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4 timing ablations)", g_gemm_variant);
     VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
@@ -432,7 +482,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
         VT_CHECK_LAUNCH("vt_gemm_nt(skinny)");
         return VT_OK;
     }
-    bool big = (g_gemm_variant >= 2 && g_gemm_variant != 7) || p.colsum_partial;
+    bool big = (g_gemm_variant >= 2 && g_gemm_variant != 7 && g_gemm_variant != 16) || p.colsum_partial;
     if (g_gemm_variant == 0 && !big && p.N >= 192 && p.M >= 192) {
         // cost in units of one full round of 192x192 tiles (256 workgroups, one per CU).  A partly filled last round of
         // that kernel costs a whole round; the 128x128 kernel runs two workgroups per CU (512 per round, a round ~1.05 of
@@ -460,13 +510,45 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     a.tiles_m = (p.M + BM - 1) / BM;
     a.tiles_n = (p.N + BN - 1) / BN;
     const dim3 grid(a.tiles_m * a.tiles_n), block(256);
-    const size_t lds = 4 * TILE_B;
     hipStream_t s = (hipStream_t)stream;
+    // At most one workgroup per CU (one or two clips per GPU): the 4-deep ring hides the load latency that a co-resident
+    // workgroup would otherwise cover (same MFMA order, bit-identical results; tile 16 forces it, tile 1 keeps the 2-deep ring)
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const bool deep = g_gemm_variant == 16 || (g_gemm_variant == 0 && (int)grid.x <= n_cu && p.K >= 4 * BK);
+    if (deep) {
+        static bool attr_set = false;
+        constexpr int LDS4 = 4 * 2 * TILE_B;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<VT_EPI_BF16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<VT_EPI_BF16_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<VT_EPI_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<VT_EPI_BF16_DGELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+            if (e != hipSuccess) {
+                vt_set_error("vt_gemm_nt: hipFuncSetAttribute(%d bytes of LDS) failed: %s", LDS4, hipGetErrorString(e));
+                return VT_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+        switch (p.epi) {
+            case VT_EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_BF16, 4>), grid, block, LDS4, s, a); break;
+            case VT_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_BF16_GELU, 4>), grid, block, LDS4, s, a); break;
+            case VT_EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_F32, 4>), grid, block, LDS4, s, a); break;
+            case VT_EPI_BF16_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_BF16_DGELU, 4>), grid, block, LDS4, s, a); break;
+            default: vt_set_error("vt_gemm_nt: unknown epilogue %d", p.epi); return VT_ERR_INVALID;
+        }
+        VT_CHECK_LAUNCH("vt_gemm_nt(128, 4-deep)");
+        return VT_OK;
+    }
+    const size_t lds = 4 * TILE_B;
     switch (p.epi) {
-        case VT_EPI_BF16: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_BF16>, grid, block, lds, s, a); break;
-        case VT_EPI_BF16_GELU: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_BF16_GELU>, grid, block, lds, s, a); break;
-        case VT_EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_F32>, grid, block, lds, s, a); break;
-        case VT_EPI_BF16_DGELU: hipLaunchKernelGGL(gemm_nt_kernel<VT_EPI_BF16_DGELU>, grid, block, lds, s, a); break;
+        case VT_EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_BF16, 2>), grid, block, lds, s, a); break;
+        case VT_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_BF16_GELU, 2>), grid, block, lds, s, a); break;
+        case VT_EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_F32, 2>), grid, block, lds, s, a); break;
+        case VT_EPI_BF16_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<VT_EPI_BF16_DGELU, 2>), grid, block, lds, s, a); break;
         default: vt_set_error("vt_gemm_nt: unknown epilogue %d", p.epi); return VT_ERR_INVALID;
     }
     VT_CHECK_LAUNCH("vt_gemm_nt");
