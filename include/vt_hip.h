@@ -86,8 +86,16 @@ typedef struct {
                                                 two workgroups per CU, 6 = 192x192 one tile per workgroup, 7 = the M <= 64
                                                 weight-streaming kernel, 8..15 = 192x192 with every other CU starting 1..8 us late
                                                 (timing experiment, correct results), 3/4 = timing ablations with WRONG results.  Results do not depend on the choice (same fp32
-                                                summation order).  The library keeps no such setting between calls */
+                                                summation order) unless K is split, below.  The library keeps no such setting between calls */
+    void* splitk_ws; int64_t splitk_ws_bytes; /* optional workspace of vt_gemm_nt_splitk_workspace_bytes() bytes, 256-byte aligned, ZERO when first
+                                                handed over (its first 4 KiB are arrival counters the kernel returns to zero) and used by one stream
+                                                at a time.  With it, a launch of the 128x128 kernel that would leave most CUs idle (the N = 768
+                                                GEMMs of a one-clip training step: 72 tiles, K up to 3072) splits K over up to 8 workgroups per
+                                                tile; the last to arrive adds the fp32 partial sums in split order and runs the epilogue:
+                                                run-to-run bit-identical, but not the unsplit summation order.  NULL: never split */
+    int32_t splitk;                          /* 0 = automatic (needs splitk_ws), 1 = never, 2..8 = this many (tests / tuning; tile 0, 1 or 16) */
 } vtGemmNT;
+size_t vt_gemm_nt_splitk_workspace_bytes(void);
 
 int vt_gemm_nt(const vtGemmNT* p_host, vtStream stream);
 

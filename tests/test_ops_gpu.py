@@ -283,9 +283,9 @@ def test_gemm_nt_deep_ring_is_bit_identical_to_the_two_stage_kernel(hip, M, N, K
     a, b = A.cuda(), B.cuda()
     for kw in (dict(epi=hip.EPI_BF16, bias=bias), dict(epi=hip.EPI_F32, bias=bias, residual=res, round_bf16=True), dict(epi=hip.EPI_BF16_GELU, bias=bias),
                dict(epi=hip.EPI_BF16_DGELU, aux=u)):
-        two = hip.gemm_nt(a, b, tile=1, **kw)
-        deep = hip.gemm_nt(a, b, tile=16, **kw)
-        auto = hip.gemm_nt(a, b, tile=0, **kw)
+        two = hip.gemm_nt(a, b, tile=1, splitk=1, **kw)
+        deep = hip.gemm_nt(a, b, tile=16, splitk=1, **kw)
+        auto = hip.gemm_nt(a, b, tile=0, splitk=1, **kw)
         torch.cuda.synchronize()
         for x, y, z in zip(*(t if isinstance(t, tuple) else (t,) for t in (two, deep, auto))):
             assert torch.equal(x, y), kw["epi"]
@@ -293,6 +293,42 @@ def test_gemm_nt_deep_ring_is_bit_identical_to_the_two_stage_kernel(hip, M, N, K
                 assert torch.equal(x, z), kw["epi"]       # 192-tile kernels accumulate K in the same order too
     ref = (A.float() @ B.float().t() + bias.cpu()).to(torch.bfloat16)
     got = hip.gemm_nt(a, b, tile=16, epi=hip.EPI_BF16, bias=bias).cpu()
+    assert (got.float() - ref.float()).abs().max() <= 2e-2 * max(1.0, ref.float().abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,split", [(1536, 768, 3072, 0), (1536, 768, 3072, 7), (1536, 768, 2304, 4), (1536, 768, 768, 3), (3072, 768, 3072, 0),
+                                          (200, 136, 448, 3), (128, 128, 128, 2), (130, 260, 1024, 8), (1536, 768, 3072, 2)])
+def test_gemm_nt_split_k_is_deterministic_and_close_to_the_unsplit_kernel(hip, M, N, K, split):
+    """vtGemmNT.splitk_ws: launches of the 128x128 kernel that leave most CUs idle (one / two clips per GPU: N = 768, 72 or 144 tiles) give each
+    tile to several workgroups over contiguous K shares; the last to arrive adds the fp32 partial sums in split order and runs the
+    epilogue.  Checked: every epilogue, forced splits 2..8 and the automatic rule (split 0), uneven K shares (7 K-tiles over 3), ragged
+    M / N; two runs bit-identical (no atomics in the sum); against the unsplit kernel only the fp32 summation order differs; the arrival
+    counters are back to zero; the automatic rule does split the one-clip shapes and leaves the small ragged ones alone."""
+    A = bf(_rand((M, K), 800 + K))
+    B = bf(_rand((N, K), 801 + N))
+    bias = torch.from_numpy(_rand((N,), 802)).cuda()
+    res = torch.from_numpy(_rand((M, N), 803)).cuda()
+    u = bf(_rand((M, N), 804)).cuda()
+    a, b = A.cuda(), B.cuda()
+    ws = hip.splitk_workspace(a.device)
+    for kw in (dict(epi=hip.EPI_BF16, bias=bias), dict(epi=hip.EPI_F32, bias=bias, residual=res), dict(epi=hip.EPI_BF16_GELU, bias=bias),
+               dict(epi=hip.EPI_BF16_DGELU, aux=u)):
+        plain = hip.gemm_nt(a, b, splitk=1, **kw)
+        one = hip.gemm_nt(a, b, splitk=split or None, **kw)
+        one = tuple(t.clone() for t in one) if isinstance(one, tuple) else one.clone()
+        two = hip.gemm_nt(a, b, splitk=split or None, **kw)
+        torch.cuda.synchronize()
+        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+        for x, y, z in zip(*(t if isinstance(t, tuple) else (t,) for t in (plain, one, two))):
+            assert torch.equal(y, z), kw["epi"]
+            scale = max(1.0, x.float().abs().max().item())
+            tol = 1e-5 if x.dtype == torch.float32 else 2.0 ** -7          # fp32 order / one bf16 rounding step
+            assert (x.float() - y.float()).abs().max().item() <= tol * scale, (kw["epi"], (x.float() - y.float()).abs().max().item())
+            if kw["epi"] == hip.EPI_F32 and M >= 1536:
+                assert not torch.equal(x, y), "the split did not happen (same bits as the unsplit kernel)"
+    ref = (A.float() @ B.float().t() + bias.cpu()).to(torch.bfloat16)
+    got = hip.gemm_nt(a, b, epi=hip.EPI_BF16, bias=bias, splitk=split or None).cpu()
     assert (got.float() - ref.float()).abs().max() <= 2e-2 * max(1.0, ref.float().abs().max().item())
 
 

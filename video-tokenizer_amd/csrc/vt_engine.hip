@@ -18,6 +18,7 @@
 #include "vt_common.h"
 
 // VT_ATTN_BWD=fused (read once): see attn_bwd() below
+static const bool g_no_splitk = [] { const char* e = getenv("VT_GEMM_SPLITK"); return e && strcmp(e, "0") == 0; }();   // A/B switch, read once
 static const bool g_attn_bwd_fused = [] { const char* e = getenv("VT_ATTN_BWD"); return e && strcmp(e, "fused") == 0; }();
 
 namespace {
@@ -88,6 +89,7 @@ struct vtTokenizer {
     // backward scratch
     size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
     const uint32_t* seed_ctr = nullptr;   // device-side per-call counter of the stochastic VQ (graph replay), see vt_vq_forward_ctr
+    size_t splitk = 0, splitk_bytes = 0;     // vt_gemm_nt's split-K partial sums + arrival counters (zeroed by *_init_workspace)
     size_t attn_ws = 0, attn_ws_bytes = 0;   // five-product attention backward: partial dQ sums + hand-off counters (head_dim 64)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
@@ -201,6 +203,8 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
     t->delta = a.take((size_t)c.B * c.H * t->L * 4);
     t->attn_ws_bytes = g_attn_bwd_fused ? vt_attention_bwd_fused_workspace_bytes(c.B, t->L, c.H, c.D / c.H, 0) : 0;   // q_begin = 0: the largest plan
     t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
+    t->splitk_bytes = vt_gemm_nt_splitk_workspace_bytes();
+    t->splitk = a.take(t->splitk_bytes);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes((int)(Kp > (size_t)t->D4 ? Kp : t->D4)));
     t->cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);  // per-M-tile column sums out of the fc2-dgrad epilogue
@@ -306,10 +310,14 @@ extern "C" int vt_tokenizer_pack(vtTokenizer* t, const vtTokenizerTensors* P, vo
     return VT_OK;
 }
 
-static vtGemmNT nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epi, void* out, int64_t ldo) {
+// every NT GEMM of the engine carries the split-K workspace: at one or two clips per GPU the N = D GEMMs are 72 / 144 tiles and
+// vt_gemm_nt splits their K (vtGemmNT.splitk_ws); at the headline batch nothing qualifies and the field is ignored
+static vtGemmNT nt(const vtTokenizer* t, void* ws, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epi, void* out,
+                   int64_t ldo) {
     vtGemmNT p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.epi = epi; p.out = out; p.ldo = ldo;
+    if (t->splitk_bytes && !g_no_splitk) { p.splitk_ws = WS(void, t->splitk); p.splitk_ws_bytes = (int64_t)t->splitk_bytes; }
     return p;
 }
 
@@ -319,17 +327,17 @@ static int block_forward(vtTokenizer* t, const BlockBufs& b, const vtBlockTensor
     const int M = t->M, D = c.D, D3 = t->D3, D4 = t->D4;
     const vtRowMap id = {0, 0, 0};
     TRY(vt_layernorm_fwd(x_in, id, w.norm1_w, w.norm1_b, 1e-5f, M, D, WS(void, b.h1), WS(float, b.mean1), WS(float, b.rstd1), s));
-    vtGemmNT g = nt(WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
+    vtGemmNT g = nt(t, ws, WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
     TRY(vt_gemm_nt(&g, s));
     TRY(vt_attention_fwd(WS(void, b.qkv), c.B, t->L, c.H, c.D / c.H, WS(void, b.o), WS(float, b.lse), s));
-    g = nt(WS(void, b.o), D, WS(void, b.proj_wb), D, M, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
+    g = nt(t, ws, WS(void, b.o), D, WS(void, b.proj_wb), D, M, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
     g.bias = w.proj_b; g.residual = x_in; g.ldr = D;
     TRY(vt_gemm_nt(&g, s));
     TRY(vt_layernorm_fwd(WS(float, b.x_mid), id, w.norm2_w, w.norm2_b, 1e-5f, M, D, WS(void, b.h2), WS(float, b.mean2), WS(float, b.rstd2), s));
-    g = nt(WS(void, b.h2), D, WS(void, b.fc1_wb), D, M, D4, D, VT_EPI_BF16_GELU, WS(void, b.u), D4);
+    g = nt(t, ws, WS(void, b.h2), D, WS(void, b.fc1_wb), D, M, D4, D, VT_EPI_BF16_GELU, WS(void, b.u), D4);
     g.out2 = WS(void, b.g); g.ldo2 = D4; g.bias = w.fc1_b;
     TRY(vt_gemm_nt(&g, s));
-    g = nt(WS(void, b.g), D4, WS(void, b.fc2_wb), D4, M, D, D4, VT_EPI_F32, x_out, D);
+    g = nt(t, ws, WS(void, b.g), D4, WS(void, b.fc2_wb), D4, M, D, D4, VT_EPI_F32, x_out, D);
     g.bias = w.fc2_b; g.residual = WS(float, b.x_mid); g.ldr = D;
     TRY(vt_gemm_nt(&g, s));
     return VT_OK;
@@ -343,17 +351,17 @@ static int block_forward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb, 
     const vtRowMap id = {0, 0, 0};
     const vtRowMap kmap = {lb.nk, t->L, lb.q_begin};
     TRY(vt_layernorm_fwd(x_in, id, w.norm1_w, w.norm1_b, 1e-5f, M, D, WS(void, b.h1), WS(float, b.mean1), WS(float, b.rstd1), s));
-    vtGemmNT g = nt(WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
+    vtGemmNT g = nt(t, ws, WS(void, b.h1), D, WS(void, b.qkv_wb), D, M, D3, D, VT_EPI_BF16, WS(void, b.qkv), D3);
     TRY(vt_gemm_nt(&g, s));
     TRY(vt_attention_fwd_rows(WS(void, b.qkv), c.B, t->L, c.H, c.D / c.H, lb.q_begin, WS(void, b.o), WS(float, b.lse), s));
-    g = nt(WS(void, b.o), D, WS(void, b.proj_wb), D, Mk, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
+    g = nt(t, ws, WS(void, b.o), D, WS(void, b.proj_wb), D, Mk, D, D, VT_EPI_F32, WS(void, b.x_mid), D);
     g.bias = w.proj_b; g.residual = x_in; g.ldr = D; g.omap = kmap;
     TRY(vt_gemm_nt(&g, s));
     TRY(vt_layernorm_fwd(WS(float, b.x_mid), kmap, w.norm2_w, w.norm2_b, 1e-5f, Mk, D, WS(void, b.h2), WS(float, b.mean2), WS(float, b.rstd2), s));
-    g = nt(WS(void, b.h2), D, WS(void, b.fc1_wb), D, Mk, D4, D, VT_EPI_BF16_GELU, WS(void, b.u), D4);
+    g = nt(t, ws, WS(void, b.h2), D, WS(void, b.fc1_wb), D, Mk, D4, D, VT_EPI_BF16_GELU, WS(void, b.u), D4);
     g.out2 = WS(void, b.g); g.ldo2 = D4; g.bias = w.fc1_b;
     TRY(vt_gemm_nt(&g, s));
-    g = nt(WS(void, b.g), D4, WS(void, b.fc2_wb), D4, Mk, D, D4, VT_EPI_F32, x_out, D);
+    g = nt(t, ws, WS(void, b.g), D4, WS(void, b.fc2_wb), D4, Mk, D, D4, VT_EPI_F32, x_out, D);
     g.bias = w.fc2_b; g.residual = WS(float, b.x_mid); g.ldr = D; g.omap = kmap;
     TRY(vt_gemm_nt(&g, s));
     return VT_OK;
@@ -368,7 +376,7 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
     // 1. patchify + patch-embed GEMM (+bias +sincos PE) written straight into rows [0,Nv) of every sequence
     TRY(vt_patchify(video, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->patches), s));
     float* x0 = WS(float, t->x_enc[0]);
-    vtGemmNT g = nt(WS(void, t->patches), t->Kp, WS(void, t->pe_wb), t->Kp, t->Mv, D, t->Kp, VT_EPI_F32, x0, D);
+    vtGemmNT g = nt(t, ws, WS(void, t->patches), t->Kp, WS(void, t->pe_wb), t->Kp, t->Mv, D, t->Kp, VT_EPI_F32, x0, D);
     g.bias = P->pe_b; g.rowmod = P->enc_patch_pe; g.rowmod_period = Nv; g.omap = vtRowMap{Nv, L, 0};
     g.round_bf16 = 1;  // conv output is bf16 under autocast before the fp32 PE add
     TRY(vt_gemm_nt(&g, s));
@@ -387,7 +395,7 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
     if (out->input_norms)
         hipLaunchKernelGGL(rownorm_mean_kernel, dim3(2), dim3(64), 0, (hipStream_t)s, xe, (int64_t)L, (int64_t)Nv, (int64_t)L - 1, c.B, D, out->input_norms);
     TRY(vt_cast_rows(xe, qmap, t->Mq, D, WS(void, t->zb), D, s));
-    g = nt(WS(void, t->zb), D, WS(void, t->in_wb), D, t->Mq, c.d, D, VT_EPI_F32, WS(void, t->zproj), 64);
+    g = nt(t, ws, WS(void, t->zb), D, WS(void, t->in_wb), D, t->Mq, c.d, D, VT_EPI_F32, WS(void, t->zproj), 64);
     g.bias = P->in_b; g.round_bf16 = 1;
     TRY(vt_gemm_nt(&g, s));
     if (out->projected_z)
@@ -401,7 +409,7 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
     if (out->unregularized_z) TRY(copy_d2d(out->unregularized_z, WS(void, t->vq_zn), (size_t)t->Mq * c.d * 4, hs));
     if (out->regularized_z) TRY(copy_d2d(out->regularized_z, WS(void, t->vq_rz), (size_t)t->Mq * c.d * 4, hs));
     if (out->emb) TRY(copy_d2d(out->emb, WS(void, t->vq_E), (size_t)c.K * c.d * 4, hs));
-    g = nt(WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, D, 64, VT_EPI_F32, out->encoded, D);
+    g = nt(t, ws, WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, D, 64, VT_EPI_F32, out->encoded, D);
     g.bias = P->out_b; g.round_bf16 = 1;
     TRY(vt_gemm_nt(&g, s));
     VT_CHECK_LAUNCH("vt_tokenizer_encode");
@@ -414,7 +422,7 @@ extern "C" int vt_tokenizer_codes_to_encoded(vtTokenizer* t, const vtTokenizerTe
     const vtTokenizerConfig& c = t->c;
     TRY(vt_vq_prep_codebook(P->codebook, c.K, c.d, c.l2_normalized, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(void, t->vq_ws), s));
     TRY(vt_vq_gather(WS(float, t->vq_E), indices, t->Mq, c.K, c.d, nullptr, WS(void, t->vq_rzpad), 64, s));
-    vtGemmNT g = nt(WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, c.D, 64, VT_EPI_F32, encoded, c.D);
+    vtGemmNT g = nt(t, ws, WS(void, t->vq_rzpad), 64, WS(void, t->out_wb), 64, t->Mq, c.D, 64, VT_EPI_F32, encoded, c.D);
     g.bias = P->out_b; g.round_bf16 = 1;
     TRY(vt_gemm_nt(&g, s));
     return VT_OK;
@@ -438,7 +446,7 @@ extern "C" int vt_tokenizer_decode(vtTokenizer* t, const vtTokenizerTensors* P, 
     const vtRowMap vmap = {Nv, L, Nq};
     TRY(vt_layernorm_fwd(WS(float, t->x_dec[c.depth_dec]), vmap, P->head_norm_w, P->head_norm_b, 1e-6f, t->Mv, D, WS(void, t->hN),
                          WS(float, t->meanH), WS(float, t->rstdH), s));
-    vtGemmNT g = nt(WS(void, t->hN), D, WS(void, t->head_wb), D, t->Mv, t->Kp, D, VT_EPI_F32, WS(void, t->yrows), t->Kp);
+    vtGemmNT g = nt(t, ws, WS(void, t->hN), D, WS(void, t->head_wb), D, t->Mv, t->Kp, D, VT_EPI_F32, WS(void, t->yrows), t->Kp);
     g.bias = WS(float, t->head_b_perm);
     TRY(vt_gemm_nt(&g, s));
     TRY(vt_unpatchify(WS(float, t->yrows), c.B, c.C, c.T, c.S, c.pt, c.p, pred, s));
@@ -523,13 +531,13 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     void* du = WS(void, g0.du);
     void* dqkv = WS(void, g0.dqkv);
     // fc2 dgrad fused with GELU': du = (dx_out . W2) * gelu'(u)
-    vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, du, D4);
+    vtGemmNT g = nt(t, ws, dXa, D, WS(void, b.fc2_wt), D, M, D4, D, VT_EPI_BF16_DGELU, du, D4);
     g.aux = WS(void, b.u); g.ldaux = D4;
     g.colsum_partial = WS(float, g0.cs_part);  // fc1 bias gradient = column sums of du, taken in the epilogue; summed at the flush
     TRY(vt_gemm_nt(&g, s));
     queue_slab_sum(t, WS(float, g0.cs_part), (M + 191) / 192, D4, gr.fc1_b);
     // fc1 dgrad
-    g = nt(du, D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
+    g = nt(t, ws, du, D4, WS(void, b.fc1_wt), D4, M, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     // LayerNorm2 backward + residual: dx_mid = dx_out + ln_bwd(dh2) (in place in dX; bf16 copy -> dXm); column sum = proj bias grad
     int nsl = 0;
@@ -537,12 +545,12 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
                                   WS(float, g0.ln_part2), &nsl, s));
     queue_ln_reduce(t, WS(float, g0.ln_part2), nsl, D, gr.norm2_w, gr.norm2_b, gr.proj_b);
     // proj dgrad
-    g = nt(dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
+    g = nt(t, ws, dXm, D, WS(void, b.proj_wt), D, M, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
     // attention backward
     TRY(attn_bwd(t, ws, WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), 0, dqkv, s));
     // qkv dgrad
-    g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
+    g = nt(t, ws, dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     // the block's four weight gradients: queued for the grouped launch
     t->pending.push_back(tn(dXa, D, WS(void, b.g), D4, Mp, D, D4, gr.fc2_w, D4));
@@ -574,22 +582,22 @@ static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb,
     void* du = WS(void, lb.du);
     void* dqkv = WS(void, g0.dqkv);
     TRY(vt_cast_rows(dX, kmap, Mk, D, dXa, D, s));
-    vtGemmNT g = nt(dXa, D, WS(void, b.fc2_wt), D, Mk, D4, D, VT_EPI_BF16_DGELU, du, D4);
+    vtGemmNT g = nt(t, ws, dXa, D, WS(void, b.fc2_wt), D, Mk, D4, D, VT_EPI_BF16_DGELU, du, D4);
     g.aux = WS(void, b.u); g.ldaux = D4;
     g.colsum_partial = WS(float, g0.cs_part);
     TRY(vt_gemm_nt(&g, s));
     queue_slab_sum(t, WS(float, g0.cs_part), (Mk + 191) / 192, D4, gr.fc1_b);
-    g = nt(du, D4, WS(void, b.fc1_wt), D4, Mk, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
+    g = nt(t, ws, du, D4, WS(void, b.fc1_wt), D4, Mk, D, D4, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     int nsl = 0;
     TRY(vt_layernorm_bwd_partials(WS(void, t->dh), WS(float, b.x_mid), kmap, w.norm2_w, WS(float, b.mean2), WS(float, b.rstd2), dX, Mk, D, dX, nullptr,
                                   WS(float, g0.ln_part2), &nsl, s));
     queue_ln_reduce(t, WS(float, g0.ln_part2), nsl, D, gr.norm2_w, gr.norm2_b, gr.proj_b);
     TRY(vt_cast_rows(dX, kmap, Mk, D, dXm, D, s));
-    g = nt(dXm, D, WS(void, b.proj_wt), D, Mk, D, D, VT_EPI_BF16, WS(void, t->dob), D);
+    g = nt(t, ws, dXm, D, WS(void, b.proj_wt), D, Mk, D, D, VT_EPI_BF16, WS(void, t->dob), D);
     TRY(vt_gemm_nt(&g, s));
     TRY(attn_bwd(t, ws, WS(void, b.qkv), WS(void, b.o), WS(void, t->dob), WS(float, b.lse), lb.q_begin, dqkv, s));
-    g = nt(dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
+    g = nt(t, ws, dqkv, D3, WS(void, b.qkv_wt), D3, M, D, D3, VT_EPI_BF16, WS(void, t->dh), D);
     TRY(vt_gemm_nt(&g, s));
     t->pending.push_back(tn(dXa, D, WS(void, b.g), D4, Mkp, D, D4, gr.fc2_w, D4));
     t->pending.push_back(tn(du, D4, WS(void, b.h2), D, Mkp, D4, D, gr.fc1_w, D));
@@ -625,7 +633,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             // ---- head: d_pred -> patch rows (c,dt,dy,dx) -> dgrad / wgrad -> LayerNorm backward into the last Nv rows
             VT_CHECK_ARG(d_pred, "vt_tokenizer_backward: stage 0 needs d_pred");
             TRY(vt_patchify(d_pred, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->dY), s));
-            vtGemmNT g = nt(WS(void, t->dY), Kp, WS(void, t->head_wt), Kp, t->Mv, D, Kp, VT_EPI_BF16, WS(void, t->dhN), D);
+            vtGemmNT g = nt(t, ws, WS(void, t->dY), Kp, WS(void, t->head_wt), Kp, t->Mv, D, Kp, VT_EPI_BF16, WS(void, t->dhN), D);
             TRY(vt_gemm_nt(&g, s));
             vtGemmTN w = tn(WS(void, t->dY), Kp, WS(void, t->hN), D, t->Mvp, Kp, D, G->head_w, D);
             w.row_perm = WS(int32_t, t->perm);
@@ -654,7 +662,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(vt_cast_rows(dX, lmap, t->Mq, D, WS(void, t->dEncb), D, s));  // d encoded (bf16 under autocast)
             TRY(vt_colsum(WS(void, t->dEncb), 1, D, id, t->Mq, D, G->out_b, WS(void, t->cs_ws), s));
             // out_linear: dgrad -> d regularized_z [Mq,64]; wgrad -> dW_out [D,d]
-            vtGemmNT g = nt(WS(void, t->dEncb), D, WS(void, t->out_wt), D, t->Mq, 64, D, VT_EPI_F32, WS(void, t->d_rz), 64);
+            vtGemmNT g = nt(t, ws, WS(void, t->dEncb), D, WS(void, t->out_wt), D, t->Mq, 64, D, VT_EPI_F32, WS(void, t->d_rz), 64);
             TRY(vt_gemm_nt(&g, s));
             vtGemmTN w = tn(WS(void, t->dEncb), D, WS(void, t->vq_rzpad), 64, t->Mqp, D, 64, G->out_w, c.d);
             w.q_lim = c.d;
@@ -671,7 +679,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(skinny_wgrad(t, w, ws, s));
             t->set_idx = 0;
             TRY(vt_zero_rows(dX, WS(void, t->gs[0].dx_out), tmap, t->Mv, D, s));  // video-token rows get no gradient from the bottleneck
-            g = nt(WS(void, t->dz_pad), 64, WS(void, t->in_wt), 64, t->Mq, D, 64, VT_EPI_F32, dX, D);
+            g = nt(t, ws, WS(void, t->dz_pad), 64, WS(void, t->in_wt), 64, t->Mq, D, 64, VT_EPI_F32, dX, D);
             g.out2 = WS(void, t->gs[0].dx_out); g.ldo2 = D; g.omap = qmap;
             TRY(vt_gemm_nt(&g, s));
             TRY(vt_colsum(dX, 0, D, id, t->M, D, G->enc_blocks[c.depth_enc - 1].fc2_b, WS(void, t->cs_ws), s));
@@ -737,6 +745,8 @@ extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
     t->delta = a.take((size_t)B * H * L * 4);
     t->attn_ws_bytes = g_attn_bwd_fused ? vt_attention_bwd_fused_workspace_bytes(B, L, H, D / H, 0) : 0;   // 0: two-kernel backward
     t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
+    t->splitk_bytes = vt_gemm_nt_splitk_workspace_bytes();
+    t->splitk = a.take(t->splitk_bytes);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(D));
     t->cs_ws = a.take(vt_colsum_workspace_bytes(t->D4));
     t->cs_part = a.take((size_t)((t->M + 191) / 192) * t->D4 * 4);

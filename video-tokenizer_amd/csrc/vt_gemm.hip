@@ -27,7 +27,17 @@ constexpr int TILE_B = BM * BK * 2;  // 16 KiB per operand tile
 struct NTArgs {
     vtGemmNT p;
     int tiles_m, tiles_n;
+    int split;          // workgroups per output tile (split K), 1 = none
+    float* part;        // split > 1: fp32 partial tiles, [tile][split][16 acc groups][256 threads] f32x4 (what each lane holds)
+    unsigned* ctr;      // split > 1: one arrival counter per tile, zero before and after every launch
 };
+
+// split-K hand-off (Guideline 16 of the CDNA guide; the recipe vt_attention_bwd.hip measured): partial sums leave through
+// write-through stores, the arrival counter is a device-scope atomic, and the last workgroup to arrive reads all the partials
+// back past its XCD's L2 (sc1) -- in split order, its own included, so the sum does not depend on which workgroup came last.
+__device__ __forceinline__ void st_part(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 
 // [128 rows][64 k] bf16 tile, 128-B rows, 16-B chunks; physical chunk = logical ^ ((row>>1)&7)
 __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0,
@@ -43,13 +53,20 @@ __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, int64_t l
     }
 }
 
+// 16-byte LDS read the compiler does not track: the caller counts lgkmcnt itself (gemm_nt_kernel<., 4>)
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
 __device__ __forceinline__ bf16x8 frag_nt(const char* lds, int row, int lchunk) {
     return *(const bf16x8*)(lds + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
 }
 
 // NST = 2: the ring described in the header (two workgroups per CU: one's loads land under the other's MFMAs).
 // NST = 4: the same tile, same MFMA order (bit-identical results) behind a 4-deep ring filled by inline-asm LDS-DMA, counted
-//          s_waitcnt vmcnt(16) + raw s_barrier per K-tile (two K-tiles stay in flight across the barrier) -- for launches with at
+//          s_waitcnt vmcnt(16) + raw s_barrier per K-tile (two K-tiles stay in flight across the barrier), fragment reads of one
+//          half K-tile under the MFMAs of the other -- for launches with at
 //          most one workgroup per CU (M = 1536 or 3072: one or two clips per GPU), where nothing else hides the ~1 us a K-tile's
 //          loads take and the 2-deep ring ran one K-tile per load latency (fc2 forward at one clip: 48 K-tiles = 50 us on 72 CUs).
 template <int EPI, int NST>
@@ -62,12 +79,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
     const int wr = wave >> 1, wc = wave & 1;
 
     const int nwg = a.tiles_m * a.tiles_n;
-    const int sid = xcd_remap(blockIdx.x, nwg);
+    // split K: neighbouring workgroups (one XCD) take neighbouring tiles of the SAME K range, so they share operand panels in L2
+    const int sid_all = xcd_remap(blockIdx.x, nwg * a.split);
+    const int kz = sid_all / nwg, sid = sid_all - kz * nwg;
     const int tm = sid / a.tiles_n, tn = sid % a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const int nt_all = p.K / BK;
+    const int t_first = (int)((long)kz * nt_all / a.split), nt = (int)((long)(kz + 1) * nt_all / a.split) - t_first;
 
-    const bf16_t* A = (const bf16_t*)p.A;
-    const bf16_t* B = (const bf16_t*)p.B;
+    const bf16_t* A = (const bf16_t*)p.A + (int64_t)t_first * BK;
+    const bf16_t* B = (const bf16_t*)p.B + (int64_t)t_first * BK;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -75,7 +96,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / BK;
     // LDS: [buffer 0: A | B][buffer 1: A | B]
 
     const int fr = lane & 15, fq = lane >> 4;
@@ -137,22 +157,100 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
             for (int i = 0; i < 4; ++i) glds16_sv(bk, offb[i], sbase + slot * STAGE + TILE_B + (i * 256 + wave * 64) * 16);
         };
 #pragma unroll
-        for (int s_ = 0; s_ < NST - 1; ++s_)
+        for (int s_ = 0; s_ < NST; ++s_)
             if (s_ < nt) issue(s_, s_);
-        if (nt >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 2)) : "memory");   // K-tile 0 landed, the next NST-2 may fly
+        if (nt >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 1)) : "memory");   // K-tile 0 landed, the next NST-1 may fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        int slot = 0, fill = NST - 1;                       // ring positions of the K-tile being multiplied / being filled
+        // With one workgroup per CU nothing else covers a wave's fragment reads, and read-all-then-multiply ran them back to back with
+        // its MFMAs (0.68 us per K-tile, three times the MFMA time).  Software pipeline over half K-tiles instead: the reads of one half
+        // (8 x ds_read_b128) fly under the 16 MFMAs of the other, across the barrier too -- the second half of K-tile t is multiplied
+        // AFTER the barrier, out of registers, while the first fragments of K-tile t+1 are being read.  Same MFMA order per accumulator
+        // (half 0 then half 1 of every K-tile): results stay bit-identical to the 2-deep ring.
+        // The fragment reads are inline asm with hand-counted s_waitcnt lgkmcnt: hipcc's own counter tracking gives up on loads that
+        // are still pending across the loop's back edge (it emitted lgkmcnt(0) in front of the first MFMA, i.e. no overlap at all).
+        bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+        unsigned aoff[2], boff[2];                          // lane offsets of the first A / B fragment of each half inside a stage
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            aoff[kk] = (unsigned)((wr * 64 + fr) * 128 + (((kk * 4 + fq) ^ ((fr >> 1) & 7)) << 4));
+            boff[kk] = (unsigned)(TILE_B + (wc * 64 + fr) * 128 + (((kk * 4 + fq) ^ ((fr >> 1) & 7)) << 4));
+        }
+        auto frags = [&](int slot_, int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+            const unsigned sb = sbase + slot_ * STAGE;
+            const unsigned ab = sb + aoff[kk], bb = sb + boff[kk];
+            lds_read16<0>(fb[0], bb); lds_read16<2048>(fb[1], bb); lds_read16<4096>(fb[2], bb); lds_read16<6144>(fb[3], bb);
+            lds_read16<0>(fa[0], ab); lds_read16<2048>(fa[1], ab); lds_read16<4096>(fa[2], ab); lds_read16<6144>(fa[3], ab);
+        };
+        auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        };
+        int slot = 0;                                       // ring position of the K-tile being multiplied
+        frags(0, 0, fa0, fb0);
         for (int t = 0; t < nt; ++t) {
-            const bool more = t + NST - 1 < nt;
-            if (more) issue(t + NST - 1, fill);            // the slot read in iteration t-1: every wave is past that barrier
-            multiply(smem + slot * STAGE);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 2)) : "memory");   // K-tile t+1 landed
+            frags(slot, 1, fa1, fb1);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                // first half in registers, second half in flight
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + NST - 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 2)) : "memory");   // K-tile t+1 landed, t+2 and t+3 may fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                // this wave holds both halves of K-tile t
             __builtin_amdgcn_s_barrier();
+            if (t + NST < nt) issue(t + NST, slot);         // every wave has K-tile t in registers: its slot takes K-tile t+4
             slot = slot + 1 == NST ? 0 : slot + 1;
-            fill = fill + 1 == NST ? 0 : fill + 1;
+            frags(slot, 0, fa0, fb0);                       // after the last K-tile: a slot nobody uses, read and dropped
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the dropped read: nothing of it may land on the epilogue's registers
+    }
+
+    if (a.split > 1) {
+        float* mine = a.part + ((size_t)sid * a.split + kz) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st_part(mine + ((i * 4 + j) * 256 + tid) * 4, acc[i][j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every partial of this workgroup is past the L2
+        if (tid == 0) *(unsigned*)smem = __hip_atomic_fetch_add(a.ctr + sid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned arrived = *(const unsigned*)smem;
+        __syncthreads();                                   // the epilogue reuses smem
+        if ((int)arrived != a.split - 1) return;
+        if (tid == 0) __hip_atomic_store(a.ctr + sid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + (size_t)sid * a.split * (BM * BN)), 0, a.split * BM * BN * 4, 0x00020000);
+        // a read that goes past the L2 takes ~2 us whatever its size: the first three partials are requested together (192 registers
+        // while the accumulators are dead), later ones two at a time; the additions stay in split order
+        auto fetch = [&](int z, f32x4 (&dst)[16]) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                dst[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (g * 256 + tid) * 16, z * (BM * BN * 4), 16));
+        };
+        f32x4 p0[16], p1[16], p2[16];
+        fetch(0, p0);
+        fetch(1, p1);
+        if (a.split > 2) fetch(2, p2);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            f32x4 v = p0[g] + p1[g];
+            if (a.split > 2) v += p2[g];
+            acc[g >> 2][g & 3] = v;
+        }
+        for (int z = 3; z < a.split; z += 2) {
+            const bool two = z + 1 < a.split;
+            fetch(z, p0);
+            if (two) fetch(z + 1, p1);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                acc[g >> 2][g & 3] += p0[g];
+                if (two) acc[g >> 2][g & 3] += p1[g];
+            }
         }
     }
 
@@ -436,6 +534,9 @@ static void launch_skinny(const vtGemmNT& p, hipStream_t s) {
 
 }  // namespace
 
+constexpr int VT_SPLITK_CTR_BYTES = 4096;   // arrival counters (one per 128x128 output tile) in front of the partial sums
+extern "C" size_t vt_gemm_nt_splitk_workspace_bytes(void) { return VT_SPLITK_CTR_BYTES + (size_t)512 * BM * BN * 4; }   // automatic rule: tiles x split <= 2 x 256
+
 int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half);
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s);
 int vt_gemm192_init();
@@ -509,7 +610,8 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     a.p = p;
     a.tiles_m = (p.M + BM - 1) / BM;
     a.tiles_n = (p.N + BN - 1) / BN;
-    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    a.split = 1; a.part = nullptr; a.ctr = nullptr;
+    const int tiles = a.tiles_m * a.tiles_n;
     hipStream_t s = (hipStream_t)stream;
     // At most one workgroup per CU (one or two clips per GPU): the 4-deep ring hides the load latency that a co-resident
     // workgroup would otherwise cover (same MFMA order, bit-identical results; tile 16 forces it, tile 1 keeps the 2-deep ring)
@@ -518,7 +620,32 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const bool deep = g_gemm_variant == 16 || (g_gemm_variant == 0 && (int)grid.x <= n_cu && p.K >= 4 * BK);
+    // Split K (only with a caller-supplied workspace): a launch that would leave most of the chip idle -- the N = 768 GEMMs of a
+    // one- or two-clip step are 72 or 144 tiles with K up to 3072 -- gives each tile to `split` workgroups, each over a
+    // contiguous share of the K-tiles; the last one to arrive adds the fp32 partial sums in split order and runs the epilogue.
+    // Deterministic (run-to-run bit-identical), but NOT the unsplit kernel's summation order: results differ from tile 1 / 16 in
+    // the last fp32 bits.  Automatic rule from tools/gemm_small_m.py on MI355X.
+    const int nt_all = p.K / BK;
+    if (p.splitk_ws && p.splitk != 1 && (g_gemm_variant == 0 || g_gemm_variant == 1 || g_gemm_variant == 16)) {
+        int want = p.splitk;
+        if (want == 0 && g_gemm_variant == 0 && tiles < n_cu && nt_all >= 24) {
+            // the hand-off costs ~6 us (write-through stores, the counter, one read past the L2): K >= 1536 pays for it, K = 768 does not;
+            // three partials are read back in one go, more would queue behind each other
+            want = tiles * 3 <= 2 * n_cu ? 3 : 2;
+        }
+        if (want > nt_all) want = nt_all;
+        if (want >= 2) {
+            const size_t need = VT_SPLITK_CTR_BYTES + (size_t)tiles * want * BM * BN * 4;
+            VT_CHECK_ARG(tiles <= VT_SPLITK_CTR_BYTES / 4 && (size_t)p.splitk_ws_bytes >= need && ((uintptr_t)p.splitk_ws & 255) == 0,
+                         "vt_gemm_nt: split-K workspace too small or misaligned (%lld bytes, this launch needs %zu: %d tiles x %d; "
+                         "vt_gemm_nt_splitk_workspace_bytes() covers every automatic choice)", (long long)p.splitk_ws_bytes, need, tiles, want);
+            a.split = want;
+            a.ctr = (unsigned*)p.splitk_ws;
+            a.part = (float*)((char*)p.splitk_ws + VT_SPLITK_CTR_BYTES);
+        }
+    }
+    const dim3 grid(tiles * a.split), block(256);
+    const bool deep = g_gemm_variant == 16 || (g_gemm_variant == 0 && (int)grid.x <= n_cu && nt_all / a.split >= 4);
     if (deep) {
         static bool attr_set = false;
         constexpr int LDS4 = 4 * 2 * TILE_B;

@@ -27,7 +27,8 @@ class GemmNT(ctypes.Structure):
     _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("epi", c_i32), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64), ("bias", c_vp),
                 ("residual", c_vp), ("ldr", c_i64), ("rowmod", c_vp), ("rowmod_period", c_i32), ("aux", c_vp),
-                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp), ("out_scale", c_f32), ("tile", c_i32)]
+                ("ldaux", c_i64), ("omap", RowMap), ("round_bf16", c_i32), ("colsum_partial", c_vp), ("out_scale", c_f32), ("tile", c_i32),
+                ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64), ("splitk", c_i32)]
 
 
 class GemmTN(ctypes.Structure):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "vt_abi_version": (c_i32, []),
     "vt_last_error": (c_i32, [ctypes.c_char_p, c_sz]),
     "vt_gemm_nt": (c_i32, [ctypes.POINTER(GemmNT), c_vp]),
+    "vt_gemm_nt_splitk_workspace_bytes": (c_sz, []),
     "vt_gemm_tn_grouped": (c_i32, [ctypes.POINTER(GemmTN), c_i32, c_vp]),
     "vt_layernorm_fwd": (c_i32, [c_vp, RowMap, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32]),
@@ -231,9 +233,26 @@ def stream():
 # thin op-level wrappers (used by tests and by the module for the few ops outside the engine)
 # ---------------------------------------------------------------------------------------------
 
+GEMM_SPLITK = True       # False: gemm_nt never hands vt_gemm_nt a split-K workspace (A/B switch of tools and tests)
+_SPLITK_WS = {}
+
+
+def splitk_workspace(dev):
+    """the zeroed split-K workspace of vt_gemm_nt for the current stream of `dev` (one per stream: the arrival counters in its
+    first 4 KiB belong to one launch at a time)"""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(lib().vt_gemm_nt_splitk_workspace_bytes(), device=dev, dtype=torch.uint8)
+        _SPLITK_WS[key] = ws
+    return ws
+
+
 def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
-            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None, out_scale=0.0):
-    """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous)."""
+            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None, out_scale=0.0, splitk=None):
+    """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous).
+    splitk: None = the library's automatic split of K for launches that leave most CUs idle (vtGemmNT.splitk_ws; a workspace
+    per device and stream is kept here), 1 = never, 2..8 = forced (tests)."""
     require_gpu(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     M, K = A.shape
@@ -258,6 +277,11 @@ def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, r
     p.colsum_partial = colsum_partial.data_ptr() if colsum_partial is not None else None
     p.tile = GEMM_TILE if tile is None else tile
     p.out_scale = float(out_scale)
+    if splitk != 1 and GEMM_SPLITK:
+        ws = splitk_workspace(dev)
+        p.splitk_ws, p.splitk_ws_bytes, p.splitk = ws.data_ptr(), ws.numel(), 0 if splitk is None else int(splitk)
+    else:
+        p.splitk_ws, p.splitk_ws_bytes, p.splitk = None, 0, 1
     check(lib().vt_gemm_nt(ctypes.byref(p), stream()), "vt_gemm_nt")
     return (out, out2) if epi == EPI_BF16_GELU else out
 
