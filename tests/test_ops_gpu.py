@@ -332,6 +332,33 @@ def test_gemm_nt_split_k_is_deterministic_and_close_to_the_unsplit_kernel(hip, M
     assert (got.float() - ref.float()).abs().max() <= 2e-2 * max(1.0, ref.float().abs().max().item())
 
 
+@pytest.mark.gpu
+def test_gemm_nt192_gelu_table_equals_the_arithmetic_on_every_bf16_magnitude(hip):
+    """The 192x192 kernel's fc1 epilogue looks gelu(u) up in an LDS table of the bf16 patterns with |u| in [2^-16, 16) and falls back to
+    the arithmetic for a 4-column group that holds anything else; the 128x128 kernel keeps the arithmetic.  B = identity rows, so u is
+    exactly A: every bf16 exponent from 2^-40 to 2^20 in both signs, zeros, and the table's edge patterns land in the epilogue --
+    gelu(u) of the two kernels must be bit-identical (and u itself too)."""
+    import numpy as np
+    M, K = 384, 192
+    rng = np.random.default_rng(5)
+    exps = rng.integers(-40, 21, size=(M, K))
+    vals = np.ldexp(1.0 + rng.integers(0, 128, size=(M, K)) / 128.0, exps) * rng.choice([-1.0, 1.0], size=(M, K))
+    vals[::7, ::5] = 0.0
+    vals[1::7, ::5] = -0.0
+    vals[0, :8] = [2.0 ** -16, -2.0 ** -16, 2.0 ** -17 * 1.9921875, 15.9375, -15.9375, 16.0, -16.0, 2.0 ** -16 * 1.0078125]   # the table's edges
+    vals[2:6] = rng.normal(size=(4, K))          # rows that stay inside the table
+    a = torch.from_numpy(vals.astype(np.float32)).to(torch.bfloat16).cuda()
+    b = torch.eye(K, dtype=torch.bfloat16).cuda()
+    u128, g128 = hip.gemm_nt(a, b, epi=hip.EPI_BF16_GELU, tile=1, splitk=1)
+    u192, g192 = hip.gemm_nt(a, b, epi=hip.EPI_BF16_GELU, tile=2)
+    torch.cuda.synchronize()
+    assert torch.equal(u192, a) and torch.equal(u128, a)
+    assert torch.equal(g128.view(torch.int16), g192.view(torch.int16))
+    ref = torch.nn.functional.gelu(a.float()).to(torch.bfloat16)
+    # against torch: one bf16 rounding step, plus the arithmetic's own absolute error (Abramowitz-Stegun 7.1.26: 1.5e-7 on erf, times |u|)
+    assert ((g192.float() - ref.float()).abs() <= 2.0 ** -7 * ref.float().abs() + 4e-7 * a.float().abs().clamp(min=1.0)).all()
+
+
 # -------------------------------------------------------------------------------------- attention
 def _attn_ref(qkv, B, L, H, hd=64):
     q, k, v = qkv.reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)

@@ -58,6 +58,33 @@ struct NTGeo {
     static constexpr int P = PA + PB;
 };
 
+// gelu(u) of the fc1 epilogue by table.  It is applied to a value that is ALREADY bf16 (the rounded pre-activation u), so it is
+// a function of 16 bits: the 10 KiB of LDS above the 144-KiB ring hold bf16 gelu(u) for |u| in [2^-16, 16), both signs
+// (2 x 20 x 128 entries), filled once per workgroup at kernel start by gelu_erf itself -- every entry is bit-for-bit what the
+// arithmetic returns.  A wave whose 4-column group holds a value outside the range (~1e-5 of the elements) takes the arithmetic
+// for that group (wave-uniform branch), so the output is bit-identical to the arithmetic everywhere (the 128x128 kernel keeps the
+// arithmetic; tests compare the two with torch.equal).  Measured gain: 84.9 -> 82.2 us on fc1 forward at the step's shape
+// (tools/gemm_gelu_epilogue.py) -- small, because the GELU epilogue's extra 17 us over the plain one is mostly its second 75-MB
+// output, written by all 256 CUs in phase, not its ~17 VALU + v_rcp + v_exp per element.  The same table for gelu' (fp32, 16 KiB)
+// was built for the fc2-dgrad epilogue and dropped: that instantiation has no register to spare (256 allocated) and spilled
+// around the main loop.
+template <int EPI>
+struct GeluTab {
+    static constexpr bool ON = EPI == VT_EPI_BF16_GELU;
+    static constexpr int LO_EXP = 127 - 16;
+    static constexpr int NEXP = 20;
+    static constexpr int PER_SIGN = NEXP * 128;
+    static constexpr int ENTRY = 2;
+    static constexpr int BYTES = ON ? 2 * PER_SIGN * ENTRY : 0;
+    // entry index of the bf16 bit pattern `b`, or >= 2 * PER_SIGN when out of range
+    static __device__ __forceinline__ unsigned index(unsigned b) {
+        const unsigned i = (b & 0x7FFFu) - (unsigned)(LO_EXP << 7);
+        return i < (unsigned)PER_SIGN ? i + ((b >> 15) ? PER_SIGN : 0) : 0xFFFFu;
+    }
+};
+__device__ __forceinline__ unsigned bf16_bits(bf16_t x) { return (unsigned)__builtin_bit_cast(unsigned short, x); }
+__device__ __forceinline__ bf16_t bf16_from_bits(unsigned b) { return __builtin_bit_cast(bf16_t, (unsigned short)b); }
+
 // The P 16-B-per-lane DMA pieces of a K-tile (pieces 0..PA-1 = A rows, PA..P-1 = B rows).  A lane's byte offset inside
 // its operand's [tile rows][K] panel does not depend on the K-tile (row clamp and swizzle are per row), so it is computed
 // once (nt192_piece_offsets) and every K-tile costs only the scalar advance of the two panel pointers: glds16_sv.
@@ -195,6 +222,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 
     set_tile(blockIdx.x);
     issue_tile(0);
+    using GT = GeluTab<EPI>;
+    constexpr bool TABLE = GT::ON && WN == 4;
+    [[maybe_unused]] char* const tab = smem + G::NST * G::STAGE;
+    if constexpr (TABLE) {
+        // visible to every wave long before the first epilogue: the main loop's barriers lie in between
+        for (int e = tid; e < 2 * GT::PER_SIGN; e += G::THREADS) {
+            const unsigned sgn = e >= GT::PER_SIGN ? 1u : 0u;
+            const float x = bf2f(bf16_from_bits((sgn << 15) | (unsigned)(e - (int)sgn * GT::PER_SIGN + (GT::LO_EXP << 7))));
+            ((bf16_t*)tab)[e] = f2bf(gelu_erf(x));
+        }
+    }
     if (a.dbg >= 8 && ((blockIdx.x >> 3) & 1))          // timing experiment (vtGemmNT.tile 8..15): every other CU of an XCD starts 1..8 us late
         for (int i = 0; i < a.dbg - 7; ++i) __builtin_amdgcn_s_sleep(32);
     constexpr bool PERSIST = WN == 4;   // the 192x96 experiment stays one tile per workgroup
@@ -266,6 +304,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 
     if constexpr (EPI != VT_EPI_F32) {
         if ((p.N & 3) == 0) {
+            // the epilogue's per-thread coordinates are recomputed per output tile: hoisted out of the persistent loop they would
+            // sit in registers across the main loop, which has none to spare (256 allocated, spill-free)
+            int tid_e = tid;
+            if constexpr (TABLE) asm volatile("" : "+v"(tid_e));
+            const int fr_e = tid_e & 15, fq_e = (tid_e & 63) >> 4;
             // bf16 outputs leave through LDS: after the swapped MFMA a lane owns 4 consecutive columns of 16 different
             // rows, so a direct store instruction touches 16 cache lines with 32 B each (the K -> 0 intercept of
             // tools/gemm_epilogue_cost.py: 2.4 TB/s of stores).  Staged as bf16(acc + bias) in a [192][TNW] image (row
@@ -280,7 +323,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             if constexpr (EPI == VT_EPI_BF16_DGELU) {
                 // the pre-activations this thread will need after the read-back: all NIT loads go out now, so their HBM
                 // latency runs under the staging writes and the barrier instead of 20 times in the store loop
-                const int c = tid % UPR, rl = tid / UPR;
+                const int c = tid_e % UPR, rl = tid_e / UPR;
                 const int n = en0 + c * 4;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -293,7 +336,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             f32x4 b4[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int n = en0 + wn * 48 + j * 16 + fq * 4;
+                const int n = en0 + wn * 48 + j * 16 + fq_e * 4;
                 b4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -301,14 +344,14 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const f32x4 v = acc[i][j] + b4[j];
-                    *(bf16x4*)(smem + (wm * 96 + i * 16 + fr) * STRIDE + (wn * 12 + j * 4 + fq) * 8) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *(bf16x4*)(smem + (wm * 96 + i * 16 + fr_e) * STRIDE + (wn * 12 + j * 4 + fq_e) * 8) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 }
             __syncthreads();
             if constexpr (EPI == VT_EPI_BF16_DGELU) {
                 // a thread keeps ONE 4-column group and walks the rows (48 lanes cover a 384-B row, the rest of the wave the
                 // next row), so the column sums of the rounded output -- the bias gradient of the Linear whose
                 // pre-activation is `aux` -- fall out of the epilogue instead of a separate pass over M x N
-                const int c = tid % UPR, rl = tid / UPR;
+                const int c = tid_e % UPR, rl = tid_e / UPR;
                 const int n = en0 + c * 4;
                 f32x4 cs = {0.f, 0.f, 0.f, 0.f};
                 if (rl < RL && n < p.N) {
@@ -330,11 +373,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     float* red = (float*)(smem + TM * STRIDE);       // [RL][TNW], behind the staged image
                     if (rl < RL) *(f32x4*)(red + rl * G::TNW + c * 4) = cs;
                     __syncthreads();
-                    if (tid < G::TNW && en0 + tid < p.N) {
+                    if (tid_e < G::TNW && en0 + tid_e < p.N) {
                         float sum = 0.f;
 #pragma unroll
-                        for (int r = 0; r < RL; ++r) sum += red[r * G::TNW + tid];
-                        p.colsum_partial[(int64_t)(em0 / TM) * p.N + en0 + tid] = sum;
+                        for (int r = 0; r < RL; ++r) sum += red[r * G::TNW + tid_e];
+                        p.colsum_partial[(int64_t)(em0 / TM) * p.N + en0 + tid_e] = sum;
                     }
                 }
                 continue;
@@ -348,22 +391,32 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 bf16x4 hh[RB];
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
-                    const int slot = (it0 + u) * G::THREADS + tid;
+                    const int slot = (it0 + u) * G::THREADS + tid_e;
                     const int row = slot / UPR, c = slot - row * UPR;
                     hh[u] = *(const bf16x4*)(smem + row * STRIDE + c * 8);
                 }
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
-                    const int slot = (it0 + u) * G::THREADS + tid;
+                    const int slot = (it0 + u) * G::THREADS + tid_e;
                     const int row = slot / UPR, c = slot - row * UPR;
                     const int m = em0 + row, n = en0 + c * 4;
                     if (m >= p.M || n >= p.N) continue;
                     const bf16x4 h = hh[u];
                     bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
                     st_stream((bf16x4*)o, h);
-                    if constexpr (EPI == VT_EPI_BF16_GELU)
-                        st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n),
-                                  (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))});
+                    if constexpr (EPI == VT_EPI_BF16_GELU) {
+                        bf16x4 gl;
+                        bool looked_up = false;
+                        if constexpr (TABLE) {
+                            const unsigned i0 = GT::index(bf16_bits(h[0])), i1 = GT::index(bf16_bits(h[1])), i2 = GT::index(bf16_bits(h[2])), i3 = GT::index(bf16_bits(h[3]));
+                            if (__builtin_amdgcn_ballot_w64(((i0 | i1 | i2 | i3) & 0x8000u) != 0) == 0) {
+                                gl = (bf16x4){((const bf16_t*)tab)[i0], ((const bf16_t*)tab)[i1], ((const bf16_t*)tab)[i2], ((const bf16_t*)tab)[i3]};
+                                looked_up = true;
+                            }
+                        }
+                        if (!looked_up) gl = (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
+                        st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n), gl);
+                    }
                 }
             }
             continue;
@@ -591,9 +644,10 @@ static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg) {
     const int persist = (WN == 4 && dbg != 5) ? g_num_cus : ntiles;
     const dim3 grid(ntiles < persist ? ntiles : persist), block(G::THREADS);
     const size_t lds = G::NST * G::STAGE;
+    constexpr size_t tab_gelu = WN == 4 ? GeluTab<VT_EPI_BF16_GELU>::BYTES : 0;
     switch (p.epi) {
         case VT_EPI_BF16: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16, WN>), grid, block, lds, s, a); break;
-        case VT_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16_GELU, WN>), grid, block, lds, s, a); break;
+        case VT_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16_GELU, WN>), grid, block, lds + tab_gelu, s, a); break;
         case VT_EPI_F32: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_F32, WN>), grid, block, lds, s, a); break;
         default: hipLaunchKernelGGL((gemm_nt192_kernel<VT_EPI_BF16_DGELU, WN>), grid, block, lds, s, a); break;
     }
@@ -621,7 +675,8 @@ int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s) {
 
 template <int EPI, int WN>
 static hipError_t allow_lds_nt() {
-    return hipFuncSetAttribute((const void*)gemm_nt192_kernel<EPI, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<WN>::NST * NTGeo<WN>::STAGE);
+    return hipFuncSetAttribute((const void*)gemm_nt192_kernel<EPI, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NTGeo<WN>::NST * NTGeo<WN>::STAGE + (WN == 4 ? GeluTab<EPI>::BYTES : 0));
 }
 
 int vt_gemm192_init() {
