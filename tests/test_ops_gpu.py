@@ -596,10 +596,15 @@ def test_gemm_nt_dgelu_fused_column_sums(hip, M, N, K, variant):
         hip.GEMM_TILE = 0
 
 
-def test_pack_weights_grouped_equals_single_packs(hip):
-    """vt_pack_weights_grouped (all bf16 operand copies of the model in a few launches) == vt_pack_weight one by one"""
+@pytest.mark.parametrize("ragged", [False, True])
+def test_pack_weights_grouped_equals_single_packs(hip, ragged):
+    """vt_pack_weights_grouped (all bf16 operand copies of the model in a few launches) == a cast / transpose in torch.  Extents that
+    are all multiples of 4 take the 64x64 kernel (16 B in, 8 B out per thread); one ragged job in a group sends that group to the
+    32x32 element-wise kernel"""
     import ctypes
     shapes = [(768, 768), (2304, 768), (24, 768), (768, 24), (100, 36)] * 8     # 40 jobs: two grouped launches
+    if ragged:
+        shapes[3], shapes[37] = (33, 50), (7, 129)
     ws = [torch.from_numpy(_rand(sh, 400 + i)).cuda() for i, sh in enumerate(shapes)]
     perm = torch.randperm(100).to(torch.int32).cuda()
     jobs = (hip.PackJob * len(shapes))()

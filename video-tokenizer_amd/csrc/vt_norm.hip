@@ -518,20 +518,65 @@ extern "C" int vt_pack_weight(const float* w, int32_t N, int32_t K, const int32_
     return VT_OK;
 }
 
+// 64x64 tiles, 16 bytes in / 8 bytes out per thread: a row of the tile is a whole 256-B (fp32 read) or 128-B (bf16 write) line in
+// both the row-major and the transposed copy; the 32x32 kernel above wrote 64-B half lines and ran at 2.3 TB/s of the 8 B/element
+// it moves.  Needs K, N, ldd, lddT multiples of 4 and 16-/8-byte aligned bases (every tokenizer weight); other jobs take the kernel above.
+__global__ __launch_bounds__(256) void pack_weight_group64_kernel(const PackGroup g) {
+    __shared__ float tile[64][65];
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.tile_start[j + 1]) ++j;
+    const vtPackJob& q = g.job[j];
+    const int local = blockIdx.x - g.tile_start[j];
+    const int tiles_k = (q.K + 63) / 64;
+    const int n0 = (local / tiles_k) * 64, k0 = (local % tiles_k) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16
+    bf16_t* wb = (bf16_t*)q.wb;
+    bf16_t* wt = (bf16_t*)q.wt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + i * 16, k = k0 + tx * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < q.N && k < q.K) {
+            const int sn = q.row_perm ? q.row_perm[n] : n;
+            v = *(const f32x4*)(q.w + (int64_t)sn * q.K + k);
+            if (wb) *(bf16x4*)(wb + (int64_t)n * q.ldd + k) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[ty + i * 16][tx * 4 + r] = v[r];
+    }
+    if (!wt) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + i * 16, n = n0 + tx * 4;
+        if (n < q.N && k < q.K)
+            *(bf16x4*)(wt + (int64_t)k * q.lddT + n) = (bf16x4){f2bf(tile[tx * 4][ty + i * 16]), f2bf(tile[tx * 4 + 1][ty + i * 16]),
+                                                               f2bf(tile[tx * 4 + 2][ty + i * 16]), f2bf(tile[tx * 4 + 3][ty + i * 16])};
+    }
+}
+
 extern "C" int vt_pack_weights_grouped(const vtPackJob* jobs, int32_t n, vtStream stream) {
     VT_CHECK_ARG(jobs && n > 0, "vt_pack_weights_grouped: bad arguments");
     for (int base = 0; base < n; base += VT_PACK_MAX_GROUP) {
         PackGroup g;
         g.n = n - base < VT_PACK_MAX_GROUP ? n - base : VT_PACK_MAX_GROUP;
-        g.tile_start[0] = 0;
+        bool wide = true;
         for (int i = 0; i < g.n; ++i) {
             const vtPackJob& q = jobs[base + i];
             VT_CHECK_ARG(q.w && (q.wb || q.wt) && q.N > 0 && q.K > 0, "vt_pack_weights_grouped[%d]: bad arguments", base + i);
             VT_CHECK_ARG((!q.wb || q.ldd >= q.K) && (!q.wt || q.lddT >= q.N), "vt_pack_weights_grouped[%d]: leading dimension too small", base + i);
-            g.job[i] = q;
-            g.tile_start[i + 1] = g.tile_start[i] + ((q.N + 31) / 32) * ((q.K + 31) / 32);
+            wide = wide && q.K % 4 == 0 && q.N % 4 == 0 && q.ldd % 4 == 0 && q.lddT % 4 == 0 && ((uintptr_t)q.w & 15) == 0 &&
+                   ((uintptr_t)q.wb & 7) == 0 && ((uintptr_t)q.wt & 7) == 0;
         }
-        hipLaunchKernelGGL(pack_weight_group_kernel, dim3(g.tile_start[g.n]), dim3(256), 0, (hipStream_t)stream, g);
+        const int edge = wide ? 64 : 32;
+        g.tile_start[0] = 0;
+        for (int i = 0; i < g.n; ++i) {
+            const vtPackJob& q = jobs[base + i];
+            g.job[i] = q;
+            g.tile_start[i + 1] = g.tile_start[i] + ((q.N + edge - 1) / edge) * ((q.K + edge - 1) / edge);
+        }
+        if (wide) hipLaunchKernelGGL(pack_weight_group64_kernel, dim3(g.tile_start[g.n]), dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(pack_weight_group_kernel, dim3(g.tile_start[g.n]), dim3(256), 0, (hipStream_t)stream, g);
     }
     VT_CHECK_LAUNCH("vt_pack_weights_grouped");
     return VT_OK;
