@@ -449,6 +449,12 @@ int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* tk);
 size_t vt_tokenizer_status_offset(const vtTokenizer* tk);
 /* device-side per-call counter of the stochastic quantizer (see vt_vq_forward_ctr); NULL (the default) = the by-value seed alone */
 int vt_tokenizer_set_seed_counter(vtTokenizer* tk, const uint32_t* seed_counter);
+/* Split K in the BACKWARD input-gradient GEMMs that would leave most CUs idle (vtGemmNT.splitk_ws; one or two clips per GPU): on by
+ * default (VT_GEMM_SPLITK=0 in the environment starts every handle with it off).  Forward GEMMs are never split: a clip's tokens and
+ * reconstruction do not depend on the batch it runs in.  With the split, its GRADIENTS are summed in a different fp32 order than in a
+ * larger batch and, re-rounded to bf16 layer after layer, differ from them at the bf16 noise level (~5e-3 relative on the deepest
+ * layers) instead of ~1e-6: switch it off where bit-stable gradients across batch sizes matter more than the ~8 % it buys. */
+int vt_tokenizer_set_split_k(vtTokenizer* tk, int32_t on);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);
@@ -469,6 +475,7 @@ int vt_stack_create(const vtStackConfig* cfg, vtStack** out);
 void vt_stack_destroy(vtStack* st);
 size_t vt_stack_workspace_bytes(const vtStack* st);
 int vt_stack_init_workspace(vtStack* st, void* ws, vtStream stream);
+int vt_stack_set_split_k(vtStack* st, int32_t on);   /* as vt_tokenizer_set_split_k */
 int vt_stack_forward(vtStack* st, const vtBlockTensors* blocks_host, const float* x_in, void* ws, float* x_out, vtStream stream);
 int vt_stack_backward(vtStack* st, const vtBlockTensors* blocks_host, const float* dy, void* ws, const vtBlockTensors* grads_host,
                       float* dx, int32_t need_wgrad, vtStream stream);

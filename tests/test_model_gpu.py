@@ -297,28 +297,40 @@ def test_config_B_eight_clips_equal_the_sum_of_single_clip_runs():
     LayerNorm), so the 8-clip gradients must equal the SUM of eight 1-clip runs with the VQ loss weighted 1/8
     (loss_q is a mean over the batch's tokens).  Forward outputs of a clip do not depend on its neighbours at all (bit-equal);
     weight gradients differ only by the fp32 summation order over clips (MFMA accumulation over 12 288 rows vs eight partial
-    sums added afterwards): rel-L2 1e-5."""
+    sums added afterwards): rel-L2 1e-5 -- with K unsplit; with the 1-clip default (split K in the backward) see (b) below."""
     cfg = O.make_cfg("B")
     model, _ = build(cfg, seed=13)
     B = 8
     x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 83)).cuda()
     w = torch.from_numpy(gen.normal(tuple(x.shape), 84)).cuda()
     model.train()
-    out8, g8 = _grads_of(model, x, w, 0.7)
-    pred8, idx8 = out8["pred_frames"].clone(), out8["bottleneck_rep"].clone()
-    assert len(torch.unique(idx8)) >= 0.25 * idx8[0].numel()
-    acc = {n: torch.zeros_like(g, dtype=torch.float64) for n, g in g8.items()}
-    for i in range(B):
-        out1, g1 = _grads_of(model, x[i:i + 1], w[i:i + 1], 0.7 / B)
-        assert torch.equal(out1["bottleneck_rep"], idx8[i:i + 1]), i
-        assert rel(out1["pred_frames"], pred8[i:i + 1]) < 1e-6, i
-        for n, g in g1.items():
-            acc[n] += g.double()
-    bad = [(n, rel(g8[n], acc[n])) for n in g8]
-    assert all(e < 1e-5 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:6]
-    # and the whole 8-clip step is run-to-run bit-reproducible (no atomics anywhere in the step)
-    _, again = _grads_of(model, x, w, 0.7)
-    assert all(torch.equal(again[n], g8[n]) for n in g8)
+    # (a) K unsplit everywhere: every per-clip quantity of a 1-clip run is bit-identical to the 8-clip run's, only the sums over clips differ
+    # (b) the default: K of the backward input-gradient GEMMs under 256 tiles split (vt_tokenizer_set_split_k; every N = 768 dgrad of a
+    #     1-clip run, the decoder's last block at 8 clips): the forward is still bit-equal; the gradients carry a different fp32 summation
+    #     order through 24 layers of bf16 re-rounding and agree at the bf16 noise level (measured 4-6e-3 on the deepest layers), not 1e-5
+    first = None
+    for split_k, tol in ((False, 1e-5), (True, 2e-2)):
+        model._engine.set_split_k(split_k)
+        out8, g8 = _grads_of(model, x, w, 0.7)
+        pred8, idx8 = out8["pred_frames"].clone(), out8["bottleneck_rep"].clone()
+        assert len(torch.unique(idx8)) >= 0.25 * idx8[0].numel()
+        if first is None:
+            first = (pred8, idx8)
+        assert torch.equal(idx8, first[1]) and torch.equal(pred8, first[0])          # the forward does not depend on the switch
+        acc = {n: torch.zeros_like(g, dtype=torch.float64) for n, g in g8.items()}
+        for i in range(B):
+            out1, g1 = _grads_of(model, x[i:i + 1], w[i:i + 1], 0.7 / B)
+            assert torch.equal(out1["bottleneck_rep"], idx8[i:i + 1]), i
+            assert rel(out1["pred_frames"], pred8[i:i + 1]) < 1e-6, i
+            for n, g in g1.items():
+                acc[n] += g.double()
+        bad = [(n, rel(g8[n], acc[n])) for n in g8]
+        assert all(e < tol for _, e in bad), (split_k, sorted(bad, key=lambda t: -t[1])[:6])
+        if split_k:
+            assert max(e for _, e in bad) > 1e-5, "K was not split in the 1-clip backward"
+        # and the whole 8-clip step is run-to-run bit-reproducible in either mode (no atomics in any sum)
+        _, again = _grads_of(model, x, w, 0.7)
+        assert all(torch.equal(again[n], g8[n]) for n in g8), split_k
 
 
 def test_encode_and_decode_are_differentiable_on_their_own():

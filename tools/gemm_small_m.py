@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import video_tokenizer_amd.hip as hip  # noqa: E402
 
 D = 768
-CASES = [("2-deep", dict(tile=1, splitk=1)), ("4-deep", dict(tile=16, splitk=1))] + [(f"split{s}", dict(tile=0, splitk=s)) for s in (2, 3, 4, 6, 7, 8)] + [("auto", dict(tile=0))]
+CASES = [("2-deep", dict(tile=1, splitk=1)), ("4-deep", dict(tile=16, splitk=1))] + [(f"split{s}", dict(tile=0, splitk=s)) for s in (2, 3, 4, 6, 7, 8)] + [("auto", dict(tile=0, splitk=None))]
 for M in (1536, 3072):
     for name, N, K, epi in (("qkv fwd", 3 * D, D, hip.EPI_BF16), ("proj", D, D, hip.EPI_F32), ("fc1 fwd", 4 * D, D, hip.EPI_BF16_GELU), ("fc2 fwd", D, 4 * D, hip.EPI_F32),
                             ("fc1 dgrad", D, 4 * D, hip.EPI_BF16), ("qkv dgrad", D, 3 * D, hip.EPI_BF16)):

@@ -89,6 +89,8 @@ struct vtTokenizer {
     // backward scratch
     size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
     const uint32_t* seed_ctr = nullptr;   // device-side per-call counter of the stochastic VQ (graph replay), see vt_vq_forward_ctr
+    bool splitk_on = !g_no_splitk;           // vt_tokenizer_set_split_k / vt_stack_set_split_k; VT_GEMM_SPLITK=0 starts it off
+    bool in_backward = false;                // set by the entry points: nt() hands the split-K workspace to backward GEMMs only
     size_t splitk = 0, splitk_bytes = 0;     // vt_gemm_nt's split-K partial sums + arrival counters (zeroed by *_init_workspace)
     size_t attn_ws = 0, attn_ws_bytes = 0;   // five-product attention backward: partial dQ sums + hand-off counters (head_dim 64)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
@@ -221,6 +223,12 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
 extern "C" void vt_tokenizer_destroy(vtTokenizer* t) { delete t; }
 extern "C" size_t vt_tokenizer_workspace_bytes(const vtTokenizer* t) { return t ? t->ws_bytes : 0; }
 extern "C" int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* t) { return t ? 3 + t->c.depth_enc + t->c.depth_dec : 0; }
+extern "C" int vt_tokenizer_set_split_k(vtTokenizer* t, int32_t on) {
+    VT_CHECK_ARG(t, "vt_tokenizer_set_split_k: null handle");
+    t->splitk_on = on != 0;
+    return VT_OK;
+}
+extern "C" int vt_stack_set_split_k(vtStack* t, int32_t on) { return vt_tokenizer_set_split_k(t, on); }
 extern "C" int vt_tokenizer_set_seed_counter(vtTokenizer* t, const uint32_t* seed_counter) {
     VT_CHECK_ARG(t, "vt_tokenizer_set_seed_counter: null handle");
     t->seed_ctr = seed_counter;
@@ -310,14 +318,16 @@ extern "C" int vt_tokenizer_pack(vtTokenizer* t, const vtTokenizerTensors* P, vo
     return VT_OK;
 }
 
-// every NT GEMM of the engine carries the split-K workspace: at one or two clips per GPU the N = D GEMMs are 72 / 144 tiles and
-// vt_gemm_nt splits their K (vtGemmNT.splitk_ws); at the headline batch nothing qualifies and the field is ignored
+// the input-gradient GEMMs of the engine carry the split-K workspace: at one or two clips per GPU the N = D GEMMs are 72 / 144 tiles
+// and vt_gemm_nt splits their K (vtGemmNT.splitk_ws); at the headline batch nothing qualifies and the field is ignored
 static vtGemmNT nt(const vtTokenizer* t, void* ws, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epi, void* out,
                    int64_t ldo) {
     vtGemmNT p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.epi = epi; p.out = out; p.ldo = ldo;
-    if (t->splitk_bytes && !g_no_splitk) { p.splitk_ws = WS(void, t->splitk); p.splitk_ws_bytes = (int64_t)t->splitk_bytes; }
+    // backward only: the forward pass of a clip stays bit-identical whatever batch it runs in (sampled token ids, reconstructions);
+    // its gradients already differ across batch sizes in the last fp32 bits (summation over the batch's rows)
+    if (t->splitk_bytes && t->in_backward && t->splitk_on) { p.splitk_ws = WS(void, t->splitk); p.splitk_ws_bytes = (int64_t)t->splitk_bytes; }
     return p;
 }
 
@@ -370,6 +380,7 @@ static int block_forward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb, 
 extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, const float* video, void* ws,
                                    const vtTokenizerOutputs* out, uint64_t seed, vtStream s) {
     VT_CHECK_ARG(t && P && video && ws && out, "vt_tokenizer_encode: null pointer");
+    t->in_backward = false;
     VT_CHECK_ARG(out->encoded && out->indices && out->losses, "vt_tokenizer_encode: encoded/indices/losses outputs are required");
     const vtTokenizerConfig& c = t->c;
     const int D = c.D, L = t->L, Nv = t->Nv, Nq = c.Nq;
@@ -419,6 +430,7 @@ extern "C" int vt_tokenizer_encode(vtTokenizer* t, const vtTokenizerTensors* P, 
 extern "C" int vt_tokenizer_codes_to_encoded(vtTokenizer* t, const vtTokenizerTensors* P, const int64_t* indices, void* ws,
                                              float* encoded, vtStream s) {
     VT_CHECK_ARG(t && P && indices && ws && encoded, "vt_tokenizer_codes_to_encoded: null pointer");
+    t->in_backward = false;
     const vtTokenizerConfig& c = t->c;
     TRY(vt_vq_prep_codebook(P->codebook, c.K, c.d, c.l2_normalized, WS(float, t->vq_E), WS(float, t->vq_wnorm), WS(void, t->vq_ws), s));
     TRY(vt_vq_gather(WS(float, t->vq_E), indices, t->Mq, c.K, c.d, nullptr, WS(void, t->vq_rzpad), 64, s));
@@ -430,6 +442,7 @@ extern "C" int vt_tokenizer_codes_to_encoded(vtTokenizer* t, const vtTokenizerTe
 
 extern "C" int vt_tokenizer_decode(vtTokenizer* t, const vtTokenizerTensors* P, const float* encoded, void* ws, float* pred, vtStream s) {
     VT_CHECK_ARG(t && P && encoded && ws && pred, "vt_tokenizer_decode: null pointer");
+    t->in_backward = false;
     const vtTokenizerConfig& c = t->c;
     const int D = c.D, L = t->L, Nv = t->Nv, Nq = c.Nq;
     float* x0 = WS(float, t->x_dec[0]);
@@ -615,6 +628,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
                                      const vtTokenizerTensors* G, int32_t stage_begin, int32_t stage_end, int32_t* final_through,
                                      vtStream s) {
     VT_CHECK_ARG(t && P && ws && G && G->enc_blocks && G->dec_blocks, "vt_tokenizer_backward: null pointer");
+    t->in_backward = true;
     const vtTokenizerConfig& c = t->c;
     const int nstage = vt_tokenizer_num_backward_stages(t);
     VT_CHECK_ARG(stage_begin >= 0 && stage_end <= nstage && stage_begin <= stage_end, "vt_tokenizer_backward: bad stage range");
@@ -766,6 +780,7 @@ extern "C" int vt_stack_init_workspace(vtStack* t, void* ws, vtStream stream) {
 
 extern "C" int vt_stack_forward(vtStack* t, const vtBlockTensors* blocks, const float* x_in, void* ws, float* x_out, vtStream s) {
     VT_CHECK_ARG(t && blocks && x_in && ws && x_out, "vt_stack_forward: null pointer");
+    t->in_backward = false;
     const int depth = t->c.depth_enc;
     const size_t bytes = (size_t)t->M * t->c.D * 4;
     hipStream_t hs = (hipStream_t)s;
@@ -781,6 +796,7 @@ extern "C" int vt_stack_forward(vtStack* t, const vtBlockTensors* blocks, const 
 extern "C" int vt_stack_backward(vtStack* t, const vtBlockTensors* blocks, const float* dy, void* ws, const vtBlockTensors* grads,
                                  float* dx, int32_t need_wgrad, vtStream s) {
     VT_CHECK_ARG(t && blocks && dy && ws && grads && dx, "vt_stack_backward: null pointer");
+    t->in_backward = true;
     const int depth = t->c.depth_enc, D = t->c.D;
     const size_t bytes = (size_t)t->M * D * 4;
     const vtRowMap id = {0, 0, 0};

@@ -148,6 +148,7 @@ class TokenizerEngine:
         self.segments = None  # stage -> (lo, hi) element range of the flat gradient buffer
         self.reducer = None   # set by parallel.DataParallelTokenizer
         self.seed_counter = 0
+        self.split_k = None   # None = the library's default (on unless VT_GEMM_SPLITK=0); set_split_k() overrides it for every geometry
         self.graph_mode = False   # GraphedStep: weights are re-packed inside the captured step, the VQ seed counter lives on the device
 
     def __deepcopy__(self, memo):
@@ -225,8 +226,17 @@ class TokenizerEngine:
             c.inv_tau, c.beta, c.codebook_w = inv_tau, beta, cw
             c.freeze_codebook = int(frozen)
             st = _State(self, key, c, device)
+            if self.split_k is not None:
+                hip.check(hip.lib().vt_tokenizer_set_split_k(st.handle, int(self.split_k)), "vt_tokenizer_set_split_k")
             self.states[key] = st
         return st
+
+    def set_split_k(self, on):
+        """Split K in the backward input-gradient GEMMs at one / two clips per GPU (vt_tokenizer_set_split_k): +8 % there, at the price of
+        gradients that agree with a larger batch's only to the bf16 noise level.  Forward results never depend on it."""
+        self.split_k = bool(on)
+        for st in self.states.values():
+            hip.check(hip.lib().vt_tokenizer_set_split_k(st.handle, int(self.split_k)), "vt_tokenizer_set_split_k")
 
     def ensure_packed(self, st, pstruct):
         v = self.params_version()

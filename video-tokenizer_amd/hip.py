@@ -176,6 +176,8 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_num_backward_stages": (c_i32, [c_vp]),
     "vt_tokenizer_status_offset": (c_sz, [c_vp]),
     "vt_tokenizer_set_seed_counter": (c_i32, [c_vp, c_vp]),
+    "vt_tokenizer_set_split_k": (c_i32, [c_vp, c_i32]),
+    "vt_stack_set_split_k": (c_i32, [c_vp, c_i32]),
     "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, ctypes.POINTER(c_i32), c_vp]),
 }
 
@@ -249,10 +251,11 @@ def splitk_workspace(dev):
 
 
 def gemm_nt(A, B, epi=EPI_BF16, bias=None, out=None, out2=None, residual=None, rowmod=None, rowmod_period=0,
-            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None, out_scale=0.0, splitk=None):
+            aux=None, omap=None, round_bf16=False, out_rows=None, colsum_partial=None, tile=None, out_scale=0.0, splitk=1):
     """C = A @ B.T with the fused epilogue `epi`; A [M,K] bf16, B [N,K] bf16 (row-major, contiguous).
-    splitk: None = the library's automatic split of K for launches that leave most CUs idle (vtGemmNT.splitk_ws; a workspace
-    per device and stream is kept here), 1 = never, 2..8 = forced (tests)."""
+    splitk: 1 = never split K (default: the result's bits do not depend on how many rows share the launch), None = the library's
+    automatic split for launches that leave most CUs idle (vtGemmNT.splitk_ws; a workspace per device and stream is kept here),
+    2..8 = forced (tests)."""
     require_gpu(A, B)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     M, K = A.shape
