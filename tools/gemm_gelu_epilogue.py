@@ -15,7 +15,13 @@ out2 = torch.empty_like(out)
 cs = torch.empty((M + 191) // 192, 4 * D, device="cuda")
 cases = {"plain bf16": dict(epi=hip.EPI_BF16, bias=bias, out=out),
          "fc1 GELU": dict(epi=hip.EPI_BF16_GELU, bias=bias, out=out, out2=out2),
-         "fc2-dgrad DGELU": dict(epi=hip.EPI_BF16_DGELU, aux=u, out=out, colsum_partial=cs)}
+         "fc2-dgrad DGELU": dict(epi=hip.EPI_BF16_DGELU, aux=u, out=out, colsum_partial=cs),
+         # timing ablations (wrong results): where does the epilogue's time go?
+         "plain, no stores": dict(epi=hip.EPI_BF16, bias=bias, out=out, tile=17),
+         "plain, stores stay in cache": dict(epi=hip.EPI_BF16, bias=bias, out=out, tile=18),
+         "GELU, no stores / no gelu": dict(epi=hip.EPI_BF16_GELU, bias=bias, out=out, out2=out2, tile=17),
+         "GELU, stores stay in cache": dict(epi=hip.EPI_BF16_GELU, bias=bias, out=out, out2=out2, tile=18),
+         "plain, one tile per WG": dict(epi=hip.EPI_BF16, bias=bias, out=out, tile=6)}
 res = {}
 for _ in range(5):
     for name, kw in cases.items():
@@ -30,4 +36,4 @@ for _ in range(5):
         res.setdefault(name, []).append(e0.elapsed_time(e1) / 20 * 1e3)
 for name, v in res.items():
     med = sorted(v)[len(v) // 2]
-    print(f"{name:16s} {med:6.1f} us  ({2.0 * M * 4 * D * D / med / 1e6:.0f} TF/s)", flush=True)
+    print(f"{name:28s} {med:6.1f} us  ({2.0 * M * 4 * D * D / med / 1e6:.0f} TF/s)", flush=True)

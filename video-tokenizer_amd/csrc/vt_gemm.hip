@@ -544,7 +544,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
     const int g_gemm_variant = p.tile;   // per call (vtGemmNT.tile); the library holds no tile setting of its own
-    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 16, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4 timing ablations)", g_gemm_variant);
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 18, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4/17/18 timing ablations)", g_gemm_variant);
     VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
@@ -600,7 +600,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant == 6 ? 5 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
+        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant == 6 ? 5 : g_gemm_variant >= 17 ? g_gemm_variant - 1 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
         const int half = g_gemm_variant == 5;
         vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half);
         VT_CHECK_LAUNCH("vt_gemm_nt(192)");

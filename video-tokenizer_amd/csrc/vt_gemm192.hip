@@ -34,7 +34,7 @@ __device__ __forceinline__ void raw_barrier() {
 struct NT192Args {
     vtGemmNT p;
     int tiles_m, tiles_n;
-    int dbg;      // timing experiments only (vtGemmNT.tile 3/4): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads
+    int dbg;      // timing experiments only (vtGemmNT.tile 3/4/17/18): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads, 16 = no bf16 output stores, 17 = output stores onto a cache-resident region
 };
 
 // Geometry of the two NT instantiations.  WN = waves along N (each wave owns 96 x 48 outputs):
@@ -384,6 +384,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             }
             // read-back in batches of RB image reads followed by their stores: with one read in flight per store (the compiler's order for
             // the plain loop) every store waits a full LDS round trip
+            // timing ablation (tile 18): every store of this workgroup lands on ONE tile-sized, cache-resident region (wave-uniform shift)
+            const int64_t dbg_shift = a.dbg == 17 ? ((int64_t)((int)(blockIdx.x & 63) * TM - em0) * p.ldo - en0) : 0;
             constexpr int NITS = TM * UPR / G::THREADS, RB = 3;
             static_assert(NITS % RB == 0, "read-back batches");
 #pragma unroll 1
@@ -402,7 +404,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     const int m = em0 + row, n = en0 + c * 4;
                     if (m >= p.M || n >= p.N) continue;
                     const bf16x4 h = hh[u];
-                    bf16_t* o = (bf16_t*)p.out + (int64_t)m * p.ldo + n;
+                    if (a.dbg == 16 && bf16_bits(h[0]) != 0x7FC1u) continue;          // timing ablation (tile 17): no output stores
+                    bf16_t* o = (bf16_t*)p.out + dbg_shift + (int64_t)m * p.ldo + n;
                     st_stream((bf16x4*)o, h);
                     if constexpr (EPI == VT_EPI_BF16_GELU) {
                         bf16x4 gl;
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                             }
                         }
                         if (!looked_up) gl = (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
-                        st_stream((bf16x4*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n), gl);
+                        st_stream((bf16x4*)((bf16_t*)p.out2 + dbg_shift + (int64_t)m * p.ldo2 + n), gl);
                     }
                 }
             }
