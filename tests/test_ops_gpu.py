@@ -366,6 +366,29 @@ def _attn_ref(qkv, B, L, H, hd=64):
     return (att @ v).transpose(1, 2).reshape(B * L, H * hd)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,H,hd,Bbig", [(1536, 12, 64, 8), (256, 12, 32, 24), (320, 3, 64, 64)])
+def test_attention_of_a_clip_does_not_depend_on_its_batch(hip, L, H, hd, Bbig):
+    """Sequences are independent through the three attention kernels and nothing in them depends on the launch size: outputs, log-sum-exps
+    and gradients of a sequence must be bit-identical whether it is attended alone (144 workgroups at the step's shape) or inside a large
+    batch -- the property the engine's batch-independent forward rests on, and the check that held a four-deep K/V ring for small launches
+    to its claim (tools/attn_small_batch.py: bit-identical, and no faster -- 25.3 vs 25.4 us forward, 65.4 vs 61.8 us backward at one
+    clip: a lone wave per SIMD is bound by its own S -> softmax -> P.V sequence, not by the loads; the ring was not kept)."""
+    qkv = bf(_rand((Bbig * L, 3 * H * hd), 900 + L)).cuda()
+    dO = bf(_rand((Bbig * L, H * hd), 901 + L)).cuda()
+    o_big, lse_big = hip.attention_fwd(qkv, Bbig, L, H, hd=hd)
+    d_big = hip.attention_bwd(qkv, o_big, dO, lse_big, Bbig, L, H, hd=hd)
+    for b in (0, Bbig - 1):
+        rows = slice(b * L, (b + 1) * L)
+        q1 = qkv[rows].contiguous()
+        o1, lse1 = hip.attention_fwd(q1, 1, L, H, hd=hd)
+        d1 = hip.attention_bwd(q1, o1, dO[rows].contiguous(), lse1, 1, L, H, hd=hd)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o_big[rows]), b
+        assert torch.equal(lse1.reshape(-1), lse_big.reshape(Bbig, -1)[b]), b
+        assert torch.equal(d1, d_big[rows]), b                     # dQ | dK | dV: the backward kernels' rings are chosen the same way
+
+
 # head_dim 32 + odd L: the GAN discriminator's attention (loss.py:119-204: 12 heads of 32, cls token => L = 1025)
 @pytest.mark.parametrize("B,L,H,hd", [(1, 64, 1, 64), (2, 192, 3, 64), (1, 100, 2, 64), (1, 333, 1, 64),
                                       (1, 64, 1, 32), (2, 192, 3, 32), (1, 129, 2, 32), (1, 333, 4, 32)])
