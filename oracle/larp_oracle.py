@@ -209,12 +209,21 @@ def vq_forward(z, emb_weight, mode="L", l2_normalized=True, beta=0.25, codebook_
 
 
 def bottleneck_forward(x, p, prefix, mode="L", emu=False, **vq_kw):
-    """bottleneck.py:170-188: norm stats, in_linear (+ the LayerNorm of norm = 'ln_d' / 'ln_nd', :146-159: fp32, autocast off; its
-    presence is read off the state dict), regulariser, out_linear."""
+    """bottleneck.py:170-188: norm stats, in_linear (+ the LayerNorm of norm = 'ln_d' / 'ln_nd' or the batch norm of 'bn_bn' / 'bn_b',
+    :146-159: fp32, autocast off; which one is read off the state dict), regulariser, out_linear."""
     n_first = torch.norm(x[:, 0, :], dim=-1).mean()
     n_last = torch.norm(x[:, -1, :], dim=-1).mean()
     z = linear(x, p[prefix + "in_linear.weight"], p[prefix + "in_linear.bias"], emu)
-    if prefix + "norm_layer.weight" in p:
+    if prefix + "norm_layer.running_mean" in p:
+        # norm = 'bn_bn' / 'bn_b' (:115-119, 149-156): SyncBatchNorm in training mode = batch statistics (biased variance, eps 1e-5) per
+        # latent channel over (batch, tokens), or per (token, channel) over the batch; which of the two is read off the weight's length
+        w, b_ = p[prefix + "norm_layer.weight"], p[prefix + "norm_layer.bias"]
+        zf = z.float()
+        if w.numel() == zf.shape[-1]:
+            z = F.batch_norm(zf.transpose(1, 2), None, None, w, b_, True, 0.1, 1e-5).transpose(1, 2)
+        else:
+            z = F.batch_norm(zf.reshape(zf.shape[0], -1), None, None, w, b_, True, 0.1, 1e-5).reshape(zf.shape)
+    elif prefix + "norm_layer.weight" in p:
         w = p[prefix + "norm_layer.weight"]
         z = F.layer_norm(z.float(), tuple(w.shape), w, p[prefix + "norm_layer.bias"], 1e-5)
     reg = vq_forward(z, p[prefix + "regularizer.embedding.weight"], mode, **vq_kw)

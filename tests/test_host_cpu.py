@@ -82,9 +82,15 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         vt.make(s)
     s = spec_from_cfg(cfg)
-    s["args"]["bottleneck"]["args"]["norm"] = "bn_bn"
-    with pytest.raises(NotImplementedError):
+    s["args"]["bottleneck"]["args"]["norm"] = "bn_xx"
+    with pytest.raises(ValueError):
         vt.make(s)
+    for bn, width in (("bn_bn", cfg["bottleneck_dim"]), ("bn_b", cfg["bottleneck_dim"] * cfg["bottleneck_token_num"])):    # bottleneck.py:115-119
+        s = spec_from_cfg(cfg)
+        s["args"]["bottleneck"]["args"]["norm"] = bn
+        m = vt.make(s)
+        assert m._composed and isinstance(m.bottleneck.norm_layer, torch.nn.SyncBatchNorm) and m.bottleneck.norm_layer.num_features == width
+        assert "bottleneck.norm_layer.running_mean" in m.state_dict()
 
 
 def test_constructor_options_of_the_composed_path_keep_the_reference_state_dict():

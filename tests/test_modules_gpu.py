@@ -99,9 +99,9 @@ def test_transformer_encoder_fused_frozen_weights_still_give_input_grad():
     assert all(q.grad is None for q in m.parameters())
 
 
-def _bottleneck(d, K, D, n, stochastic=False):
+def _bottleneck(d, K, D, n, stochastic=False, norm="none"):
     import video_tokenizer_amd as vt
-    return vt.make({"name": "bottleneck", "args": {"bottleneck_dim": d, "norm": "none", "regularizer": {"name": "vq", "args": {
+    return vt.make({"name": "bottleneck", "args": {"bottleneck_dim": d, "norm": norm, "regularizer": {"name": "vq", "args": {
         "codebook_size": K, "commitment_loss_weight": 0.25, "codebook_loss_weight": 1.0, "entropy_loss_weight": 0.0,
         "entropy_loss_temperature": 0.01, "l2_normalized": True, "stochastic": stochastic, "stochastic_temperature": 0.03}}}},
         args={"token_nums": n, "input_dim": D, "output_dim": D})
@@ -142,6 +142,55 @@ def test_bottleneck_and_vq_standalone(d, K, D, B, n):
         assert torch.equal(m.regularizer.get_codebook_entry(out["bottleneck_rep"], shape=(B * n, d)), zq.reshape(B * n, d))
         xh = m.decode(out["bottleneck_rep"])
         assert rel(xh.cpu(), ref["output"].detach()) < 2e-2
+
+
+@pytest.mark.parametrize("norm", ["ln_d", "ln_nd", "bn_bn", "bn_b"])
+def test_bottleneck_norm_variants_standalone(norm):
+    """bottleneck.py:113-126, 146-159: the norm between in_linear and the quantizer -- LayerNorm over d / over (tokens, d), SyncBatchNorm over
+    (batch, tokens) per channel ('bn_bn') / over the batch per (token, channel) ('bn_b'), fp32 with autocast off, training-mode batch
+    statistics.  Module level, on an input whose batch entries differ by order one (a norm over six samples divides by their spread: fed
+    the tokenizer's nearly batch-independent latents it amplifies bf16 rounding by the ratio of common part to spread, which no tolerance
+    survives -- a property of the option, the same in the reference).  projected_z, outputs, losses, dx and every parameter gradient
+    against the oracle following the device's indices; running statistics move as torch's momentum rule says."""
+    d, K, D, B, n = 16, 256, 128, 6, 24
+    m = _bottleneck(d, K, D, n, norm=norm)
+    width = {"ln_d": (d,), "ln_nd": (n, d), "bn_bn": (d,), "bn_b": (n * d,)}[norm]
+    sd = {"in_linear.weight": _T(gen.xavier_uniform((d, D), 41)), "in_linear.bias": _T(gen.uniform((d,), 42, -0.02, 0.02)),
+          "out_linear.weight": _T(gen.xavier_uniform((D, d), 43)), "out_linear.bias": _T(gen.uniform((D,), 44, -0.02, 0.02)),
+          "regularizer.embedding.weight": _T(gen.kaiming_uniform_codebook(K, d, 45)),
+          "norm_layer.weight": _T(gen.uniform(width, 46, 0.8, 1.2)), "norm_layer.bias": _T(gen.uniform(width, 47, -0.1, 0.1))}
+    if norm.startswith("bn"):
+        sd.update({"norm_layer.running_mean": torch.zeros(width), "norm_layer.running_var": torch.ones(width), "norm_layer.num_batches_tracked": torch.tensor(0)})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = _T(gen.normal((B, n, D), 48)).requires_grad_(True)
+    w = _T(gen.normal((B, n, D), 49))
+    xg = x.detach().cuda().requires_grad_(True)
+    out = m(xg)
+    ((out["output"] * w.cuda()).sum() + 0.7 * out["loss_q"]).backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    idx = out["bottleneck_rep"].cpu()
+    ref = O.bottleneck_forward(x, p, "", "L", emu=True, force_idx=idx)
+    ((ref["output"] * w).sum() + 0.7 * ref["loss_q"]).backward()
+    free = O.bottleneck_forward(x.detach(), sd, "", "L", emu=True)
+    assert (free["bottleneck_rep"] == idx).float().mean().item() >= 0.95
+    for k in ("output", "projected_z", "regularized_z"):
+        assert rel(out[k].cpu().float(), ref[k].detach()) < 2e-2, k
+    np.testing.assert_allclose(float(out["loss_q"]), float(ref["loss_q"]), rtol=2e-2)
+    assert rel(xg.grad.cpu(), x.grad) < 6e-2
+    top = max(float(p[k].grad.norm()) for k, _ in m.named_parameters())
+    for k, q in m.named_parameters():
+        g = p[k].grad
+        if norm.startswith("bn") and k == "in_linear.bias":
+            assert float(g.norm()) < 1e-3 * top and float(q.grad.norm()) < 1e-3 * top      # a batch norm removes the constant in front of it (up to the bf16 rounding of z)
+        else:
+            assert rel(q.grad.cpu(), g) < 6e-2, (k, rel(q.grad.cpu(), g))
+    if norm.startswith("bn"):
+        z = (x.detach().reshape(-1, D) @ sd["in_linear.weight"].t() + sd["in_linear.bias"]).reshape(B, n, d)
+        mean = z.mean(dim=(0, 1)) if norm == "bn_bn" else z.mean(dim=0).reshape(-1)
+        assert int(m.norm_layer.num_batches_tracked) == 1
+        assert rel(m.norm_layer.running_mean.cpu(), 0.1 * mean) < 2e-2
 
 
 DISC_TINY = dict(hidden=128, n_heads=4, n_layers=2, input_size=32, frame_num=4, pt=2, ps=8)   # head_dim 32, L = 33

@@ -1,7 +1,7 @@
 """Bottleneck + vector quantiser: parameter holders and option surface.
 
 Mirrors /root/reference/models/bottleneck.py: `Bottleneck` (:65-188; in_linear -> regulariser ->
-out_linear, norm='none' only) and `SimpleVectorQuantizer` (:203-344; l2-normalised cosine / L2
+out_linear; norm 'none' on the fused engine, the LayerNorm / SyncBatchNorm variants as torch glue on the composed path) and `SimpleVectorQuantizer` (:203-344; l2-normalised cosine / L2
 codebook search in three index modes).  State-dict keys: `in_linear.*`, `out_linear.*`,
 `regularizer.embedding.weight`.  Arithmetic: vt_vq_forward / vt_vq_backward + GEMMs -- fused inside the
 engine when called through LARPTokenizer, through functional.{Linear,VectorQuantize} when the modules are
@@ -118,9 +118,7 @@ class Bottleneck(nn.Module):
             raise NotImplementedError("bottleneck_dim <= 0 (identity projections) is not built")
         self.bottleneck_dim = bottleneck_dim
         norm = None if norm is None or norm.lower() in ("no", "none") else norm.lower()
-        if norm in ("bn_bn", "bn_b"):
-            raise NotImplementedError(f"bottleneck norm '{norm}' (SyncBatchNorm over the batch) is not built (the tokenizer yamls use 'none')")
-        if norm not in (None, "ln_d", "ln_nd", "ln_d_na"):
+        if norm not in (None, "ln_d", "ln_nd", "ln_d_na", "bn_bn", "bn_b"):
             raise ValueError(f"Normalization type {norm} not supported")
         self.norm = norm
         if regularizer is None or regularizer["name"].lower() != "vq":
@@ -137,6 +135,11 @@ class Bottleneck(nn.Module):
             self.norm_layer = nn.LayerNorm((self.token_nums, self.project_dim))
         elif norm == "ln_d_na":
             self.norm_layer = nn.LayerNorm(self.project_dim, elementwise_affine=False)
+        elif norm == "bn_bn":      # bottleneck.py:115-116: one statistic per latent channel, over batch and tokens
+            self.norm_layer = nn.SyncBatchNorm(self.project_dim)
+        elif norm == "bn_b":       # :117-119: one statistic per (token, channel), over the batch only
+            assert self.token_nums is not None, "num_tokens must be specified for batch normalization"
+            self.norm_layer = nn.SyncBatchNorm(self.project_dim * self.token_nums)
         regularizer["args"]["dim"] = self.bottleneck_dim
         regularizer["args"]["token_nums"] = self.token_nums
         self.regularizer = make(regularizer)
@@ -147,6 +150,10 @@ class Bottleneck(nn.Module):
         z = Linear.apply(x, self.in_linear.weight, self.in_linear.bias)
         if self.norm in ("ln_d", "ln_nd"):          # (the reference applies no layer for 'ln_d_na' in project_in either, :146-159)
             z = self.norm_layer(z.float())
+        elif self.norm == "bn_bn":                  # :149-152  b n d -> b d n, SyncBatchNorm over (b, n), back; fp32, autocast off.  torch's
+            z = self.norm_layer(z.float().transpose(1, 2)).transpose(1, 2)      # module: batch statistics are all-reduced over the process group
+        elif self.norm == "bn_b":                   # :153-156  b n d -> b (n d)
+            z = self.norm_layer(z.float().reshape(z.shape[0], -1)).reshape(z.shape)
         return z
 
     def project_out(self, z_cat):
