@@ -223,6 +223,82 @@ def test_discriminator_matches_oracle_forward_and_all_gradients():
     _check_param_grads(m, p)
 
 
+def _sn_effective(sd, train_step):
+    """torch.nn.utils.parametrizations.spectral_norm restated on a state dict: for every `X.parametrizations.weight.original` the effective
+    weight X.weight = W / sigma, sigma = u . (W_mat v), after one power-iteration step (u <- normalize(W_mat v), v <- normalize(W_mat^T u),
+    eps 1e-12: torch's order) when `train_step`, with the stored u, v otherwise.  Returns (effective dict with differentiable entries, leaves, new u)."""
+    leaves, eff, new_u = {}, {}, {}
+    for k, v in sd.items():
+        if k.endswith(".parametrizations.weight.original"):
+            base = k[:-len(".parametrizations.weight.original")]
+            W = v.clone().requires_grad_(True)
+            leaves[k] = W
+            u, vv = sd[base + ".parametrizations.weight.0._u"].clone(), sd[base + ".parametrizations.weight.0._v"].clone()
+            Wm = W.flatten(1)
+            if train_step:
+                with torch.no_grad():
+                    u = torch.nn.functional.normalize(Wm @ vv, dim=0, eps=1e-12)
+                    vv = torch.nn.functional.normalize(Wm.t() @ u, dim=0, eps=1e-12)
+            new_u[base] = u
+            eff[base + ".weight"] = W / torch.dot(u, Wm @ vv)
+        elif ".parametrizations." not in k:
+            t = v.clone()
+            if t.is_floating_point() and k != "encoder_pos_embed":
+                t.requires_grad_(True)
+                leaves[k] = t
+            eff[k] = t
+    return eff, leaves, new_u
+
+
+@pytest.mark.parametrize("train_step", [False, True])
+def test_discriminator_with_spectral_norm(train_step):
+    """loss.py:59-64, 275-276 `spectral_norm=True`: every Conv3d / Linear of the discriminator under torch's spectral-norm parametrization.
+    Logits and the gradient of every ORIGINAL weight (through W / sigma and through the HIP kernels) against the oracle fed with the
+    restated effective weights -- in eval mode (stored u, v) and in training mode, where exactly ONE power-iteration step per layer and
+    forward must have happened (the stored u afterwards equals the restated step: the kernels' wrappers read each `.weight` once)."""
+    import video_tokenizer_amd as vt
+    c = DISC_TINY
+    spec = {"name": "lpips_disc_loss", "args": dict(
+        disc_type="transformer", disc_start=0, disc_self_start=-1, pixelloss_weight=1.0, perceptual_weight=0.0, pixel_loss="l1",
+        lecam_weight=0.0, disc_loss="ns", disc_weight=0.3, r1_gp_weight=0.0, d_update_freq=1, spectral_norm=True,
+        disc_tran_hidden_size=c["hidden"], disc_tran_n_heads=c["n_heads"], disc_tran_n_layers=c["n_layers"],
+        disc_tran_temporal_patch_size=c["pt"], disc_tran_patch_size=c["ps"], input_spatial_size=c["input_size"], frame_num=c["frame_num"])}
+    torch.manual_seed(5)
+    lm = vt.make(spec)
+    D = lm.discriminator
+    plain = O.init_discriminator_state_dict(c["hidden"], c["n_heads"], c["n_layers"], c["input_size"], c["frame_num"], c["pt"], c["ps"])
+    sd = D.state_dict()
+    n_sn = 0
+    for k in list(sd.keys()):
+        if k.endswith(".parametrizations.weight.original"):
+            sd[k] = plain[k.replace(".parametrizations.weight.original", ".weight")].clone()
+            n_sn += 1
+        elif k in plain:
+            sd[k] = plain[k].clone()
+    assert n_sn == 2 + 4 * c["n_layers"]                      # patch-embed conv, fc, and qkv / proj / fc1 / fc2 of every block
+    D.load_state_dict(sd, strict=True)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    D = D.cuda()
+    D.train(train_step)
+    x = _T(gen.video_clips(2, c["frame_num"], c["input_size"], 61))
+    w = _T(gen.normal((2, 1), 62))
+    logits = D(x.cuda())
+    (logits * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    eff, leaves, new_u = _sn_effective(sd, train_step)
+    ref = O.discriminator_forward(eff, c, x, emu=True)
+    (ref * w).sum().backward()
+    assert rel(logits.detach().cpu(), ref.detach()) < 2e-2
+    got = dict(D.named_parameters())
+    for k, leaf in leaves.items():
+        assert got[k].grad is not None, k
+        # 1e-1, not the 6e-2 of the plain discriminator test: W / sigma is 2-3 x the xavier weights, the attention logits grow with it and
+        # the bf16 rounding of the softmax path with them (measured: 0.068 on one qkv weight, < 0.05 elsewhere)
+        assert rel(got[k].grad.cpu(), leaf.grad) < 1e-1, (k, rel(got[k].grad.cpu(), leaf.grad))
+    for base, u in new_u.items():
+        assert rel(D.state_dict()[base + ".parametrizations.weight.0._u"].cpu(), u) < 1e-4, base
+
+
 def test_lpips_disc_loss_generator_and_discriminator_branches():
     import video_tokenizer_amd as vt
     c = DISC_TINY

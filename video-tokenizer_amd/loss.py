@@ -16,7 +16,7 @@ LPIPS (`perceptual_loss='lpips'`, weight 1.0 in the shipped yamls) is lpips.py: 
 package's state-dict layout, frozen, weights from a user-supplied state dict (env VT_LPIPS_WEIGHTS or the checkpoint's
 `loss` entry) -- parity unpinned, the package is not importable here; a callable `perceptual_loss(input_frames,
 recon_frames) -> tensor` is accepted too.  Not built (raise at construction): r1_gp_weight > 0 (needs double backward
-through the HIP ops); spectral_norm; temporal_patch_size == 1 (VideoPatchEmbed); disc_type other than 'transformer'.
+through the HIP ops); temporal_patch_size == 1 (VideoPatchEmbed); disc_type other than 'transformer'.
 """
 import os
 from itertools import chain
@@ -135,6 +135,20 @@ class TransformerDiscriminator(nn.Module):
         return rb(F.linear(rb(z_cls), rb(self.fc.weight)) + self.fc.bias)
 
 
+def _spectral_normalise(module):
+    """loss.py:59-64, 275-276: every Conv3d / Linear of the discriminator gets torch's spectral-norm parametrization (`weight` = original /
+    sigma, one power-iteration step per training forward; state-dict keys `...parametrizations.weight.original` / `.0._u` / `.0._v`, the
+    reference's).  The layers of this build are parameter holders whose `.weight` the HIP autograd functions read once per forward, so the
+    parametrized tensor -- ordinary differentiable torch ops on a [out, in] matrix -- is what the kernels consume and what their
+    weight gradients flow back through."""
+    from torch.nn.utils.parametrizations import spectral_norm
+    for name, layer in module.named_children():
+        if isinstance(layer, (nn.Conv2d, nn.Conv3d, nn.Linear)):
+            setattr(module, name, spectral_norm(layer))
+        else:
+            _spectral_normalise(layer)
+
+
 @register("lpips_disc_loss")
 class VQLPIPSWithDiscriminator(nn.Module):
     def __init__(self, disc_start, disc_self_start=None, pixelloss_weight=1.0, disc_type="transformer", disc_in_channels=3,
@@ -175,7 +189,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                                                       patch_size=disc_tran_patch_size, in_channels=disc_in_channels, frame_num=frame_num)
         self.disc_type = "3d"
         if spectral_norm:
-            raise NotImplementedError("spectral_norm=True is not built (shipped yamls set false)")
+            _spectral_normalise(self.discriminator)
         self.discriminator_iter_start = disc_start
         self.discriminator_self_start = disc_self_start if (disc_self_start is not None and disc_self_start >= 0) else disc_start
         self.disc_factor = disc_factor
