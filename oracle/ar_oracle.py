@@ -28,11 +28,11 @@ def find_multiple(n, k):
 
 
 def make_cfg(dim=384, n_layer=2, n_head=6, vocab_size=512, max_seq_len=64, num_classes=10, cls_token_num=1, norm_eps=1e-5,
-             multiple_of=256, frame_prediction=False, use_fixed_pe=False, class_dropout_prob=0.1):
+             multiple_of=256, frame_prediction=False, use_fixed_pe=False, class_dropout_prob=0.1, n_kv_head=None):
     hidden = find_multiple(int(2 * (4 * dim) / 3), multiple_of)                       # larp_ar.py:125-131
     return dict(dim=dim, n_layer=n_layer, n_head=n_head, vocab_size=vocab_size, max_seq_len=max_seq_len, num_classes=num_classes,
                 cls_token_num=cls_token_num, norm_eps=norm_eps, hidden=hidden, frame_prediction=frame_prediction, use_fixed_pe=use_fixed_pe,
-                class_dropout_prob=class_dropout_prob, multiple_of=multiple_of)
+                class_dropout_prob=class_dropout_prob, multiple_of=multiple_of, n_kv_head=n_head if n_kv_head is None else n_kv_head)
 
 
 def init_state_dict(cfg, seed=77, head_std=0.02):
@@ -50,7 +50,7 @@ def init_state_dict(cfg, seed=77, head_std=0.02):
     p["tok_embeddings.weight"] = nrm((V + (1 if cfg["frame_prediction"] else 0), D))
     for i in range(cfg["n_layer"]):
         pre = f"layers.{i}."
-        p[pre + "attention.wqkv.weight"] = nrm((3 * D, D))
+        p[pre + "attention.wqkv.weight"] = nrm(((cfg["n_head"] + 2 * cfg.get("n_kv_head", cfg["n_head"])) * (D // cfg["n_head"]), D))   # larp_ar.py:171-175
         p[pre + "attention.wo.weight"] = nrm((D, D))
         p[pre + "feed_forward.w1.weight"] = nrm((I, D))
         p[pre + "feed_forward.w3.weight"] = nrm((I, D))
@@ -72,11 +72,15 @@ def rmsnorm(x, w, eps):
     return x * torch.rsqrt(torch.mean(x * x, dim=-1, keepdim=True) + eps) * w
 
 
-def attention(x, wqkv, wo, n_head, emu=False):
-    """larp_ar.py:182-213 without a cache: causal softmax(q k^T / sqrt(hd)) v, n_kv_head == n_head"""
+def attention(x, wqkv, wo, n_head, emu=False, n_kv_head=None):
+    """larp_ar.py:182-213 without a cache: causal softmax(q k^T / sqrt(hd)) v; with n_kv_head < n_head every K / V head serves
+    n_head // n_kv_head consecutive query heads (`repeat_interleave`, :202-203)"""
     b, n, d = x.shape
     hd = d // n_head
-    q, k, v = (t.reshape(b, n, n_head, hd).transpose(1, 2) for t in linear(x, wqkv, None, emu).split(d, dim=-1))
+    n_kv = n_head if n_kv_head is None else n_kv_head
+    q, k, v = linear(x, wqkv, None, emu).split([d, n_kv * hd, n_kv * hd], dim=-1)
+    q = q.reshape(b, n, n_head, hd).transpose(1, 2)
+    k, v = (t.reshape(b, n, n_kv, hd).transpose(1, 2).repeat_interleave(n_head // n_kv, dim=1) for t in (k, v))
     s = (q @ k.transpose(-2, -1)) / math.sqrt(hd)
     s = s.masked_fill(~torch.tril(torch.ones(n, n, dtype=torch.bool)), float("-inf"))
     o = _rb(torch.softmax(s, dim=-1) @ v, emu).transpose(1, 2).reshape(b, n, d)
@@ -92,7 +96,7 @@ def feed_forward(x, w1, w3, w2, emu=False):
 def block(x, p, pre, cfg, emu=False):
     """larp_ar.py:216-229 (drop_path / dropouts are identity: evaluation, or rates 0)"""
     h = x + attention(rmsnorm(x, p[pre + "attention_norm.weight"], cfg["norm_eps"]), p[pre + "attention.wqkv.weight"], p[pre + "attention.wo.weight"],
-                      cfg["n_head"], emu)
+                      cfg["n_head"], emu, cfg.get("n_kv_head"))
     return h + feed_forward(rmsnorm(h, p[pre + "ffn_norm.weight"], cfg["norm_eps"]), p[pre + "feed_forward.w1.weight"], p[pre + "feed_forward.w3.weight"],
                             p[pre + "feed_forward.w2.weight"], emu)
 

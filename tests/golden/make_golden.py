@@ -279,7 +279,9 @@ def ar_cases():
     # name -> (oracle cfg kwargs, batch, seed)
     return {"class_S2": (dict(dim=384, n_layer=2, n_head=6, vocab_size=512, max_seq_len=64, num_classes=10), 2, 601),
             "frame_S2": (dict(dim=384, n_layer=2, n_head=6, vocab_size=256, max_seq_len=48, cls_token_num=16, frame_prediction=True), 2, 602),
-            "class_B1_fixedpe": (dict(dim=768, n_layer=1, n_head=12, vocab_size=320, max_seq_len=32, num_classes=5, use_fixed_pe=True), 4, 603)}
+            "class_B1_fixedpe": (dict(dim=768, n_layer=1, n_head=12, vocab_size=320, max_seq_len=32, num_classes=5, use_fixed_pe=True), 4, 603),
+            # grouped-query attention (larp_ar.py:171-203): 6 query heads on 2 K / V heads
+            "class_S2_gqa": (dict(dim=384, n_layer=2, n_head=6, n_kv_head=2, vocab_size=512, max_seq_len=64, num_classes=10), 2, 604)}
 
 
 def ar_inputs(cfg, B, seed):
@@ -300,7 +302,7 @@ def make_ar(out):
     for name, (kw, B, seed) in ar_cases().items():
         cfg = ar_oracle.make_cfg(**kw)
         sd = ar_oracle.init_state_dict(cfg, seed)
-        args = ref.ModelArgs(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"], vocab_size=cfg["vocab_size"], max_seq_len=cfg["max_seq_len"],
+        args = ref.ModelArgs(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"], n_kv_head=cfg["n_kv_head"], vocab_size=cfg["vocab_size"], max_seq_len=cfg["max_seq_len"],
                              num_classes=cfg["num_classes"], cls_token_num=cfg["cls_token_num"], frame_prediction=cfg["frame_prediction"],
                              use_fixed_pe=cfg["use_fixed_pe"], token_dropout_p=0.0, resid_dropout_p=0.0, ffn_dropout_p=0.0, class_dropout_prob=0.1)
         m = ref.LARP_AR(args)
@@ -330,13 +332,15 @@ def make_ar(out):
             res["grad/abs_pe"] = grads["abs_pe"]
         # greedy generation through the KV cache
         n_new = cfg["max_seq_len"]
-        for scale in ((1.0,) if cfg["frame_prediction"] else (1.0, 3.0)):
+        # (the reference's KV cache is allocated for n_head heads and updated with n_kv_head ones, larp_ar.py:154-158, 199: its own
+        # generation raises a shape error when they differ -- the grouped-query case has no greedy fixture)
+        for scale in (() if cfg["n_kv_head"] != cfg["n_head"] else (1.0,) if cfg["frame_prediction"] else (1.0, 3.0)):
             with m.sampling():
                 seq = ref.ar.generate(m, cond, n_new, cfg_scale=scale, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
             m.reset_caches()
             res[f"greedy_cfg{scale:g}"] = seq.numpy().astype(np.int32)
         np.savez_compressed(os.path.join(out, f"ar_{name}.npz"), **res)
-        print("ar", name, "loss", loss.item(), "logits", tuple(logits.shape), "greedy[:8]", res["greedy_cfg1"][0, :8].tolist(), missing)
+        print("ar", name, "loss", loss.item(), "logits", tuple(logits.shape), "greedy[:8]", res["greedy_cfg1"][0, :8].tolist() if "greedy_cfg1" in res else None, missing)
     # sampling filter (ar/generate.py:13-52) on a small batch of logits
     lg = torch.from_numpy(gen.normal((6, 40), 611, 2.0))
     filt = {f"k{k}_p{pp:g}": sys.modules["ar.generate"].top_k_top_p_filtering(lg.clone(), top_k=k, top_p=pp).numpy() for k, pp in ((0, 0.8), (5, 1.0), (7, 0.6), (0, 0.05))}

@@ -183,7 +183,7 @@ def build(name, **over):
     kw, B, seed = ar_cases()[name]
     cfg = A.make_cfg(**kw)
     sd = A.init_state_dict(cfg, seed)
-    args = dict(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"], vocab_size=cfg["vocab_size"], max_seq_len=cfg["max_seq_len"],
+    args = dict(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"], n_kv_head=cfg["n_kv_head"], vocab_size=cfg["vocab_size"], max_seq_len=cfg["max_seq_len"],
                 num_classes=cfg["num_classes"], cls_token_num=cfg["cls_token_num"], frame_prediction=cfg["frame_prediction"], use_fixed_pe=cfg["use_fixed_pe"],
                 token_dropout_p=0.0, resid_dropout_p=0.0, ffn_dropout_p=0.0, class_dropout_prob=0.1)
     args.update(over)
@@ -246,8 +246,9 @@ def test_greedy_generation_through_kv_cache_matches_reference(name):
         for b in range(B):
             diff = np.nonzero(got[b, :n_chk] != want[b].numpy())[0]
             assert diff.size == 0 or margin[b, diff[0]] < 2e-3, (name, scale, b, diff[:4], float(margin[b, diff[0]]))
-        agree = (got == g[f"greedy_cfg{scale:g}"]).mean()
-        print(name, "cfg", scale, "agreement with the reference's fp32 generation:", agree)
+        if f"greedy_cfg{scale:g}" in g:           # none for grouped-query attention: the reference's own KV cache raises there; this build's works
+            agree = (got == g[f"greedy_cfg{scale:g}"]).mean()
+            print(name, "cfg", scale, "agreement with the reference's fp32 generation:", agree)
 
 
 def test_graph_replayed_generation_equals_eager_loop():

@@ -45,6 +45,8 @@ def test_forward_loss_and_gradients_match_reference(name):
 @pytest.mark.parametrize("name", list(ar_cases()))
 def test_greedy_generation_matches_reference_kv_cache(name):
     cfg, sd, (tok, cond), g, B = _case(name)
+    if cfg["n_kv_head"] != cfg["n_head"]:
+        pytest.skip("the reference's own KV cache raises with n_kv_head != n_head (larp_ar.py:154-158, 199): no greedy fixture exists")
     for scale in (1.0,) if cfg["frame_prediction"] else (1.0, 3.0):
         want = g[f"greedy_cfg{scale:g}"]
         n_new = 24                                              # a prefix of the reference's full-length generation keeps this fast

@@ -11,7 +11,8 @@ vt_attention_causal_* for training / prefill, vt_decode_attention against the KV
 glue the reference also leaves to elementwise ops: embedding gathers, the absolute-PE add, dropout, residual adds, cross-entropy and the
 sampling arithmetic over [B, vocab] logits.  Mixed precision = autocast(bf16) (trainers/larp_ar_trainer.py runs under it): fp32
 parameters and residual stream, bf16 GEMM operands with fp32 accumulation, Linear outputs rounded to bf16.  GPU tensors only.
-Not built: n_kv_head != n_head (no llama-abs size uses it), `emb_masks` in generate (frame-prediction masking of the prefix).
+Grouped-query attention (n_kv_head < n_head; no llama-abs size uses it) runs on the multi-head kernels through a row-expanded wqkv
+(Attention.__init__).  Not built: `emb_masks` in generate (frame-prediction masking of the prefix).
 """
 import os
 from contextlib import contextmanager
@@ -72,6 +73,25 @@ def _pack(mod, *names):
             w = torch.cat([x.detach() for x in ws], dim=0) if len(ws) > 1 else ws[0].detach()
             hit = (key, hip.pack_weight(w.float().contiguous()))
         cache[names] = hit
+    return hit[1]
+
+
+def _wqkv(at):
+    """the [3 dim, dim] weight the attention kernels consume: the stored one, or its grouped-query row expansion (differentiable)"""
+    return at.wqkv.weight if at._gqa_rows is None else at.wqkv.weight.index_select(0, at._gqa_rows)
+
+
+def _pack_qkv(at):
+    """bf16 operand copies of _wqkv(at)"""
+    if at._gqa_rows is None:
+        return _pack(at, "wqkv")
+    w = at.wqkv.weight
+    key = (w.data_ptr(), w._version)
+    hit = at.__dict__.get("_vt_pack_gqa")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, hip.pack_weight(w.detach().index_select(0, at._gqa_rows).float().contiguous()))
+        at.__dict__["_vt_pack_gqa"] = hit
     return hit[1]
 
 
@@ -245,11 +265,24 @@ class Attention(nn.Module):
         self.dim, self.n_head = config.dim, config.n_head
         self.head_dim = config.dim // config.n_head
         self.n_kv_head = config.n_kv_head if config.n_kv_head is not None else config.n_head
-        if self.n_kv_head != self.n_head or self.head_dim != 64:
-            raise NotImplementedError("LARP_AR on this build: n_kv_head == n_head and head_dim 64 (true for every llama-abs size, larp_ar.py:449-468)")
+        if self.head_dim != 64:
+            raise NotImplementedError("LARP_AR on this build: head_dim 64 (true for every llama-abs size, larp_ar.py:449-468)")
         if config.attn_dropout_p > 0:
             raise NotImplementedError("attn_dropout_p > 0 is not built (the shipped configs use 0.0)")
-        self.wqkv = nn.Linear(config.dim, 3 * config.dim, bias=False)
+        assert self.n_head % self.n_kv_head == 0
+        # larp_ar.py:171-175: rows = q (n_head heads) | k (n_kv_head heads) | v (n_kv_head heads)
+        self.wqkv = nn.Linear(config.dim, (self.n_head + 2 * self.n_kv_head) * self.head_dim, bias=False)
+        # Grouped-query attention (n_kv_head < n_head; no shipped size uses it): `keys.repeat_interleave(n_head // n_kv_head)` (:202-203) is the
+        # same function as multi-head attention with every K / V head's weight rows repeated for its group, so the kernels run on that
+        # expanded [3 dim, dim] weight (a row gather of the stored one: its gradient sums each group back, which is the GQA gradient).
+        # It costs the repeated K / V projections and a KV cache of n_head heads; the stored parameter keeps the reference's shape.
+        if self.n_kv_head != self.n_head:
+            g, hd = self.n_head // self.n_kv_head, self.head_dim
+            kv = (torch.arange(self.n_head) // g).repeat_interleave(hd) * hd + torch.arange(hd).repeat(self.n_head)
+            rows = torch.cat([torch.arange(self.dim), self.dim + kv, self.dim + self.n_kv_head * hd + kv])
+            self.register_buffer("_gqa_rows", rows, persistent=False)
+        else:
+            self._gqa_rows = None
         self.wo = nn.Linear(config.dim, config.dim, bias=False)
         self.kv_cache = None
         self.resid_dropout = nn.Dropout(config.resid_dropout_p)
@@ -275,8 +308,8 @@ class TransformerBlock(nn.Module):
         at, ff = self.attention, self.feed_forward
         if cached:                       # inference with a KV cache: prefill (several tokens from position 0) or one-token decode
             return self._forward_cached(x, input_pos)
-        a = _AttnBranch.apply(x, self.attention_norm.weight, at.wqkv.weight, at.wo.weight, at.n_head, self.attention_norm.eps,
-                              _pack(at, "wqkv"), _pack(at, "wo"))
+        a = _AttnBranch.apply(x, self.attention_norm.weight, _wqkv(at), at.wo.weight, at.n_head, self.attention_norm.eps,
+                              _pack_qkv(at), _pack(at, "wo"))
         h = x + self._drop_path(at.resid_dropout(a))
         f = _FfnBranch.apply(h, self.ffn_norm.weight, ff.w1.weight, ff.w3.weight, ff.w2.weight, self.ffn_norm.eps, _pack(ff, "w3", "w1"), _pack(ff, "w2"))
         return h + self._drop_path(ff.ffn_dropout(f))
@@ -290,10 +323,10 @@ class TransformerBlock(nn.Module):
         x2 = x.contiguous().reshape(M, D).float()
         fuse = _decode_fusion() if M <= 64 else "0"         # decode-sized row counts: SwiGLU (and optionally RMSNorm) inside the weight-streaming GEMM
         if fuse == "norm":
-            qkv = hip.decode_norm_linear(x2, _f32(self.attention_norm.weight), self.attention_norm.eps, _pack(at, "wqkv")[0])
+            qkv = hip.decode_norm_linear(x2, _f32(self.attention_norm.weight), self.attention_norm.eps, _pack_qkv(at)[0])
         else:
             y, _ = hip.rmsnorm_fwd(x2, _f32(self.attention_norm.weight), self.attention_norm.eps)
-            qkv = hip.gemm_nt(y, _pack(at, "wqkv")[0], hip.EPI_BF16)                      # [B * T, 3D] = q | k | v
+            qkv = hip.gemm_nt(y, _pack_qkv(at)[0], hip.EPI_BF16)                          # [B * T, 3D] = q | k | v
         if T == 1:      # one new token: cache update + attention in one launch, position read on the device (graph-capturable)
             pos = input_pos if input_pos.dtype == torch.int32 else input_pos.to(torch.int32)
             o = hip.decode_attention_step(qkv, at.kv_cache.k_cache, at.kv_cache.v_cache, pos[-1:])
