@@ -15,8 +15,9 @@ formulas over B logits are torch glue.
 LPIPS (`perceptual_loss='lpips'`, weight 1.0 in the shipped yamls) is lpips.py: a torch-ops VGG-16 metric with the `lpips`
 package's state-dict layout, frozen, weights from a user-supplied state dict (env VT_LPIPS_WEIGHTS or the checkpoint's
 `loss` entry) -- parity unpinned, the package is not importable here; a callable `perceptual_loss(input_frames,
-recon_frames) -> tensor` is accepted too.  Not built (raise at construction): r1_gp_weight > 0 (needs double backward
-through the HIP ops); temporal_patch_size == 1 (VideoPatchEmbed); disc_type other than 'transformer'.
+recon_frames) -> tensor` is accepted too.  r1_gp_weight > 0 (no shipped yaml): the penalty needs the discriminator differentiated twice,
+which the single-backward HIP functions cannot give, so that one term evaluates it as plain torch ops (_discriminator_torch_ops).
+Not built (raise at construction): temporal_patch_size == 1 (VideoPatchEmbed); disc_type other than 'transformer'.
 """
 import os
 from itertools import chain
@@ -149,6 +150,37 @@ def _spectral_normalise(module):
             _spectral_normalise(layer)
 
 
+def _discriminator_torch_ops(D, x):
+    """TransformerDiscriminator.forward (loss.py:188-201) out of plain torch ops on the GPU, for the one caller that needs to differentiate
+    the discriminator TWICE: the R1 gradient penalty (loss.py:36-56, autograd.grad(..., create_graph=True) w.r.t. the real clip, then a
+    backward through that gradient into the weights).  The HIP autograd functions of this build are single-backward, so this term -- and
+    only this term, when r1_gp_weight > 0, which no shipped yaml sets -- takes the unfused path: Conv3d, LayerNorm, Linear, an explicit
+    softmax(q k^T / sqrt(d)) v and erf-GELU under bf16 autocast like the reference's modules; not a kernel of this build and never timed."""
+    b = x.shape[0]
+    H, hd = D.n_head, D.hidden_size // D.n_head
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        emb = D.x_embedder
+        tok = F.conv3d(x, emb.proj.weight, emb.proj.bias, stride=emb.proj.stride).flatten(2).transpose(1, 2).float() + D.encoder_pos_embed
+        h = torch.cat((D.cls_token.float().expand(b, -1, -1), tok), dim=1)
+        for blk in D.transformer_encoder.blocks:
+            y = F.layer_norm(h, (D.hidden_size,), blk.norm1.weight, blk.norm1.bias, 1e-5)
+            q, k, v = F.linear(y, blk.attn.qkv.weight).reshape(b, -1, 3, H, hd).permute(2, 0, 3, 1, 4)
+            att = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1) @ v
+            h = h + F.linear(att.transpose(1, 2).reshape(b, -1, D.hidden_size), blk.attn.proj.weight, blk.attn.proj.bias).float()
+            y = F.layer_norm(h, (D.hidden_size,), blk.norm2.weight, blk.norm2.bias, 1e-5)
+            h = h + F.linear(F.gelu(F.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias).float()
+        z = F.layer_norm(h[:, 0], (D.hidden_size,), D.norm_final.weight, D.norm_final.bias, 1e-6)
+        return F.linear(z, D.fc.weight, D.fc.bias).float()
+
+
+def _r1_gradient_penalty(D, real, cost):
+    """loss.py:36-56: (logits of the real clips, cost * mean_b || d logits / d real ||^2), the gradient taken with create_graph=True"""
+    real = real.detach().clone().requires_grad_(True)
+    out = _discriminator_torch_ops(D, real)
+    g = torch.autograd.grad(outputs=out, inputs=real, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    return out, g.reshape(real.shape[0], -1).float().pow(2).sum(dim=1).mean() * cost
+
+
 @register("lpips_disc_loss")
 class VQLPIPSWithDiscriminator(nn.Module):
     def __init__(self, disc_start, disc_self_start=None, pixelloss_weight=1.0, disc_type="transformer", disc_in_channels=3,
@@ -177,9 +209,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
         self.set_perceptual_eval()
         self.pixel_power = 1 if pixel_loss == "l1" else 2
         self.input_spatial_size = input_spatial_size
-        if r1_gp_weight > 0.0:
-            raise NotImplementedError("r1_gp_weight > 0 needs double backward through the HIP ops; not built (shipped yamls set 0.0)")
-        self.r1_gp_weight = r1_gp_weight
+        self.r1_gp_weight = r1_gp_weight       # > 0: the R1 term runs the discriminator as twice-differentiable torch ops (_r1_gradient_penalty)
         self.d_update_freq = d_update_freq
         self.d_update_loss_threshold = d_update_loss_threshold
         if disc_type.lower() != "transformer":
@@ -266,17 +296,24 @@ class VQLPIPSWithDiscriminator(nn.Module):
             # one pass over [real ; fake]: the discriminator has no batch-coupled op (LayerNorm and attention are per
             # clip), so this equals the reference's two calls (:417-424) and halves the launches
             nb = inputs.shape[0]
-            logits = self.discriminator(torch.cat([inputs, reconstructions.detach()], dim=0))
-            logits_real, logits_fake = logits[:nb], logits[nb:]
+            r1_gp = zero
+            if self.training and self.r1_gp_weight > 0.0:      # loss.py:415-418: the real logits come out of the penalty's own forward
+                logits_real, r1_gp = _r1_gradient_penalty(self.discriminator, inputs.contiguous(), self.r1_gp_weight)
+                logits_fake = self.discriminator(reconstructions.detach().contiguous())
+            else:
+                logits = self.discriminator(torch.cat([inputs, reconstructions.detach()], dim=0))
+                logits_real, logits_fake = logits[:nb], logits[nb:]
             if self.lecam_weight > 0.0:
                 lecam_loss = self.lecam_weight * _lecam(logits_real.mean(), logits_fake.mean(), self.lecam_ema_real, self.lecam_ema_fake)
                 self.update_lecam_ema(logits_real, logits_fake)
             else:
                 lecam_loss = zero
             d_loss = self.objective.discriminator(logits_real, logits_fake)
-            total_loss = d_loss + self.lecam_weight * lecam_loss     # (sic) the reference applies lecam_weight twice, loss.py:426-437
+            total_loss = d_loss + self.lecam_weight * lecam_loss + r1_gp     # (sic) the reference applies lecam_weight twice, loss.py:426-437
         else:
-            d_loss = lecam_loss = total_loss = logits_real = logits_fake = zero
+            d_loss = lecam_loss = total_loss = logits_real = logits_fake = r1_gp = zero
         info = {"d_total_loss": total_loss.mean().detach(), "d_lecam_loss": lecam_loss.mean().detach(), "d_loss": d_loss.mean().detach(),
                 "logits_real": logits_real.mean().detach(), "logits_fake": logits_fake.mean().detach()}
+        if self.r1_gp_weight > 0.0:
+            info["r1_gp"] = r1_gp.mean().detach()
         return total_loss, info, None
