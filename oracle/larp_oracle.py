@@ -440,7 +440,9 @@ def discriminator_forward(p, cfg, x, emu=False):
     timm Blocks, transformer.py:8-31) -> cls row -> LayerNorm(1e-6) -> Linear(D, 1).  `p` uses the module's
     state-dict keys; cfg: dict(n_heads, n_layers)."""
     b = x.shape[0]
-    tok = patch_embed3d(x, p["x_embedder.proj.weight"], p["x_embedder.proj.bias"], emu) + p["encoder_pos_embed"]
+    w = p["x_embedder.proj.weight"]
+    w = w if w.dim() == 5 else w.unsqueeze(2)        # temporal_patch_size == 1: VideoPatchEmbed's Conv2d per frame (embed.py:16-34)
+    tok = patch_embed3d(x, w, p["x_embedder.proj.bias"], emu) + p["encoder_pos_embed"]
     h = torch.cat([p["cls_token"].expand(b, -1, -1), tok], dim=1)
     for i in range(cfg["n_layers"]):
         h = block(h, p, f"transformer_encoder.blocks.{i}.", cfg["n_heads"], emu)
@@ -464,7 +466,7 @@ def init_discriminator_state_dict(hidden, n_heads, n_layers, input_size, frame_n
     def T(a):
         return torch.from_numpy(np.ascontiguousarray(a))
 
-    sd = {"x_embedder.proj.weight": T(gen.xavier_uniform((D, 3, pt, ps, ps), nxt())),
+    sd = {"x_embedder.proj.weight": T(gen.xavier_uniform((D, 3, pt, ps, ps) if pt > 1 else (D, 3, ps, ps), nxt())),
           "x_embedder.proj.bias": T(gen.uniform((D,), nxt(), -0.02, 0.02)),
           "cls_token": T(gen.uniform((1, 1, D), nxt(), -0.1, 0.1)),
           "encoder_pos_embed": T(sincos_3d(D, th, tt)).float().reshape(1, th * th * tt, D)}

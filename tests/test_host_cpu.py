@@ -190,8 +190,8 @@ def test_discriminator_and_loss_module_surface():
                                                       "disc_tran_hidden_size": 128, "disc_tran_n_heads": 4, "disc_tran_n_layers": 1,
                                                       "disc_tran_temporal_patch_size": 2, "disc_tran_patch_size": 8, "input_spatial_size": 32, "frame_num": 4}})
     assert [m_ for m_ in lm.trainable_modules()] == [lm.discriminator] and "lecam_ema_real" in lm.state_dict()
-    with pytest.raises(NotImplementedError):
-        vt.TransformerDiscriminator(128, 4, 1, 32, 1, 8, 3)
+    per_frame = vt.TransformerDiscriminator(128, 4, 1, 32, 1, 8, 3, frame_num=4)        # temporal_patch_size 1: VideoPatchEmbed (loss.py:137-138)
+    assert tuple(per_frame.x_embedder.proj.weight.shape) == (128, 3, 8, 8) and per_frame.video_token_num == 4 * 16
 
 
 def test_vq_index_mode_follows_reference_flags():

@@ -204,8 +204,11 @@ def _disc(c):
     return m.cuda(), sd
 
 
-def test_discriminator_matches_oracle_forward_and_all_gradients():
-    c = DISC_TINY
+DISC_TINY_FRAMES = dict(DISC_TINY, pt=1)      # temporal_patch_size 1: VideoPatchEmbed (the constructor's default), L = 4 * 16 + 1 = 65
+
+
+@pytest.mark.parametrize("c", [DISC_TINY, DISC_TINY_FRAMES], ids=["patch3d", "per_frame"])
+def test_discriminator_matches_oracle_forward_and_all_gradients(c):
     m, sd = _disc(c)
     B = 3
     x = _T(gen.video_clips(B, c["frame_num"], c["input_size"], 41)).requires_grad_(True)
@@ -389,10 +392,9 @@ def test_lpips_disc_loss_generator_and_discriminator_branches():
     np.testing.assert_allclose(total.item(), tot_ref.item(), rtol=2e-2)
     _check_param_grads(lm.discriminator, p, tol=8e-2)
     assert float(lm.lecam_ema_real) != 0.0 or float(lm.lecam_ema_fake) != 0.0
-    # options that are not built say so (r1_gp_weight and spectral_norm are built: their own tests above)
-    bad = dict(spec["args"], disc_tran_temporal_patch_size=1)
-    with pytest.raises(NotImplementedError):
-        vt.make({"name": "lpips_disc_loss", "args": bad})
+    # options that are not built say so (r1_gp_weight, spectral_norm and the per-frame patch embed are built: their own tests above)
+    with pytest.raises(ValueError):
+        vt.make({"name": "lpips_disc_loss", "args": dict(spec["args"], disc_type="dino")})
     # the SHIPPED spec (cfgs/larp_tokenizer.yaml:120: perceptual_weight 1.0, perceptual_loss 'lpips') constructs and runs: lpips.py is a
     # torch-ops VGG-16 metric with the lpips package's state-dict layout (parity unpinned: the package is not importable here; without
     # user-supplied weights it warns once and runs on a seeded random init)

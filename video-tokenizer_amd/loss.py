@@ -17,7 +17,7 @@ package's state-dict layout, frozen, weights from a user-supplied state dict (en
 `loss` entry) -- parity unpinned, the package is not importable here; a callable `perceptual_loss(input_frames,
 recon_frames) -> tensor` is accepted too.  r1_gp_weight > 0 (no shipped yaml): the penalty needs the discriminator differentiated twice,
 which the single-backward HIP functions cannot give, so that one term evaluates it as plain torch ops (_discriminator_torch_ops).
-Not built (raise at construction): temporal_patch_size == 1 (VideoPatchEmbed); disc_type other than 'transformer'.
+Not built (raise at construction): disc_type other than 'transformer'.
 """
 import os
 from itertools import chain
@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .embed import PatchEmbed3D, get_3d_sincos_pos_embed
+from .embed import PatchEmbed3D, VideoPatchEmbed, get_3d_sincos_pos_embed
 from .registry import register
 from .transformer import TransformerEncoderFused
 
@@ -91,11 +91,11 @@ class TransformerDiscriminator(nn.Module):
         self.patch_size = patch_size
         self.in_channels = in_channels
         self.frame_num = frame_num
-        if temporal_patch_size == 1:
-            raise NotImplementedError("TransformerDiscriminator: temporal_patch_size == 1 (VideoPatchEmbed) is not built; "
-                                      "every shipped yaml sets disc_tran_temporal_patch_size: 4")
-        assert temporal_patch_size > 1
-        self.x_embedder = PatchEmbed3D(input_size, frame_num, patch_size, temporal_patch_size, in_channels, hidden_size, bias=True)
+        if temporal_patch_size == 1:      # loss.py:137-138: every frame through a 2-D patch embed (the constructor's default; the yamls set 4)
+            self.x_embedder = VideoPatchEmbed(input_size, patch_size, in_channels, hidden_size, bias=True, frame_num=frame_num)
+        else:
+            assert temporal_patch_size > 1
+            self.x_embedder = PatchEmbed3D(input_size, frame_num, patch_size, temporal_patch_size, in_channels, hidden_size, bias=True)
         self.token_t = self.x_embedder.num_temporal_patches
         self.token_h = self.token_w = int(self.x_embedder.num_spatial_patches ** 0.5)
         self.video_token_num = video_token_num = self.x_embedder.num_spatial_patches * self.token_t
@@ -160,7 +160,8 @@ def _discriminator_torch_ops(D, x):
     H, hd = D.n_head, D.hidden_size // D.n_head
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         emb = D.x_embedder
-        tok = F.conv3d(x, emb.proj.weight, emb.proj.bias, stride=emb.proj.stride).flatten(2).transpose(1, 2).float() + D.encoder_pos_embed
+        w = emb.proj.weight if emb.proj.weight.dim() == 5 else emb.proj.weight.unsqueeze(2)      # VideoPatchEmbed: a Conv2d per frame
+        tok = F.conv3d(x, w, emb.proj.bias, stride=w.shape[2:]).flatten(2).transpose(1, 2).float() + D.encoder_pos_embed
         h = torch.cat((D.cls_token.float().expand(b, -1, -1), tok), dim=1)
         for blk in D.transformer_encoder.blocks:
             y = F.layer_norm(h, (D.hidden_size,), blk.norm1.weight, blk.norm1.bias, 1e-5)
