@@ -279,6 +279,14 @@ def test_discriminator_with_spectral_norm(train_step):
         elif k in plain:
             sd[k] = plain[k].clone()
     assert n_sn == 2 + 4 * c["n_layers"]                      # patch-embed conv, fc, and qkv / proj / fc1 / fc2 of every block
+    # the stored u, v belong to the random weights the constructor drew; give the loaded weights vectors near their own leading singular
+    # pair (perturbed, so that a training-mode power iteration visibly moves them): sigma is then ~ the spectral norm, as in a trained model
+    for k in list(sd.keys()):
+        if k.endswith(".parametrizations.weight.original"):
+            base = k[:-len("original")]
+            U, S, Vh = torch.linalg.svd(sd[k].flatten(1).double(), full_matrices=False)
+            nz = lambda t, seed: torch.nn.functional.normalize(t.float() + 0.05 * _T(gen.normal(tuple(t.shape), seed)), dim=0)
+            sd[base + "0._u"], sd[base + "0._v"] = nz(U[:, 0], 700 + len(k)), nz(Vh[0], 701 + len(k))
     D.load_state_dict(sd, strict=True)
     sd = {k: v.clone() for k, v in D.state_dict().items()}
     D = D.cuda()

@@ -143,11 +143,10 @@ def _spectral_normalise(module):
     parametrized tensor -- ordinary differentiable torch ops on a [out, in] matrix -- is what the kernels consume and what their
     weight gradients flow back through."""
     from torch.nn.utils.parametrizations import spectral_norm
-    for name, layer in module.named_children():
-        if isinstance(layer, (nn.Conv2d, nn.Conv3d, nn.Linear)):
-            setattr(module, name, spectral_norm(layer))
-        else:
-            _spectral_normalise(layer)
+    wrap = [(parent, name) for parent in module.modules() for name, child in parent.named_children()
+            if isinstance(child, (nn.Conv2d, nn.Conv3d, nn.Linear))]
+    for parent, name in wrap:
+        setattr(parent, name, spectral_norm(getattr(parent, name)))
 
 
 def _discriminator_torch_ops(D, x):
@@ -176,10 +175,10 @@ def _discriminator_torch_ops(D, x):
 
 def _r1_gradient_penalty(D, real, cost):
     """loss.py:36-56: (logits of the real clips, cost * mean_b || d logits / d real ||^2), the gradient taken with create_graph=True"""
-    real = real.detach().clone().requires_grad_(True)
-    out = _discriminator_torch_ops(D, real)
-    g = torch.autograd.grad(outputs=out, inputs=real, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True, only_inputs=True)[0]
-    return out, g.reshape(real.shape[0], -1).float().pow(2).sum(dim=1).mean() * cost
+    leaf = real.detach().clone().requires_grad_(True)
+    logits = _discriminator_torch_ops(D, leaf)
+    (slope,) = torch.autograd.grad(logits.sum(), leaf, create_graph=True)          # d(sum of logits) / d clip = every clip's own input gradient
+    return logits, cost * slope.float().flatten(1).square().sum(dim=1).mean()
 
 
 @register("lpips_disc_loss")
