@@ -303,12 +303,15 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
         pe = p["encoder_patch_pe"]
     if "encoder_patch_token_type_embed" in p:
         pe = pe + p["encoder_patch_token_type_embed"]                   # :131-134
-    tok = tok + pe[:, : tok.shape[1]]                                   # :407
     q_emb = p["encoder_latent_query_embed"].unsqueeze(0)
     if "encoder_latent_query_token_type_embed" in p:
         q_emb = q_emb + p["encoder_latent_query_token_type_embed"]      # :147-150
     q_emb = q_emb.repeat(b, 1, 1)                                       # :410
-    z = encoder_parallel(tok, q_emb, p, "encoder.", cfg["encoder_depth"], cfg["encoder_num_heads"], emu)
+    if _mrope(p):                                                       # train_type 'mrope' (:401-405): no additive PE, Encoder111 = gated RoPE layers
+        z = _mrope_stack(torch.cat([q_emb, tok], dim=1), p, "encoder111.", cfg, q_emb.shape[1], emu)[:, : q_emb.shape[1]]
+    else:
+        tok = tok + pe[:, : tok.shape[1]]                               # :407
+        z = encoder_parallel(tok, q_emb, p, "encoder.", cfg["encoder_depth"], cfg["encoder_num_heads"], emu)
     if cfg.get("bottleneck_type", "vq") == "sq":                        # :423-428
         zp = linear(z, p["sq_in_linear.weight"], p["sq_in_linear.bias"], emu)
         sq = sq_forward(zp, p["bottleneck.embedding.weight"], force_idx=vq_kw.get("force_idx"))
@@ -330,6 +333,21 @@ def tokenizer_forward(p, cfg, x, mode="L", emu=False, **vq_kw):
     return {"pred_frames": tokenizer_decode(p, cfg, encoded, emu), **out}
 
 
+def _mrope(p):
+    return "encoder111.model_layers.attn_layer.0.to_qkv.weight" in p
+
+
+def _mrope_stack(h, p, pre, cfg, n_lat, emu):
+    """Encoder111 / Decoder111 (models/model_new/base/blocks.py:1110-1178): the gated RoPE layer stack of titok_oracle over [latents ; grid
+    tokens]; depth and heads are read off the state dict, the RoPE grid off the tokenizer's patching"""
+    from . import titok_oracle as TO
+    depth = sum(1 for k in p if k.startswith(pre + "model_layers.attn_layer.") and k.endswith(".to_qkv.weight"))
+    heads = h.shape[-1] // 64
+    grid = [cfg["frame_num"] // cfg["temporal_patch_size"], cfg["token_h"], cfg["token_h"]]
+    angles = TO.rope_angles(n_lat, grid, head_dim=64)
+    return TO.residual_attention_block(h, p, pre + "model_layers.", depth, heads, angles, emu)
+
+
 def tokenizer_decode(p, cfg, encoded, emu=False):
     """LARPTokenizer.decode (/root/reference/models/larp_tokenizer.py:456-469): latents (b, Nq, D) -> video, on its own -- the
     reference's decode() is an ordinary differentiable method (decoder-only fine-tuning on cached latents)"""
@@ -345,7 +363,10 @@ def tokenizer_decode(p, cfg, encoded, emu=False):
     if "decoder_patch_query_token_type_embed" in p:
         dq = dq + p["decoder_patch_query_token_type_embed"]             # :178
     dq = dq.expand(b, -1, -1)
-    y = encoder_parallel(zz, dq, p, "decoder.", cfg["decoder_depth"], cfg["decoder_num_heads"], emu)
+    if _mrope(p):                                                       # :459-461: no latent PE, Decoder111
+        y = _mrope_stack(torch.cat([encoded, dq], dim=1), p, "decoder111.", cfg, encoded.shape[1], emu)[:, encoded.shape[1]:]
+    else:
+        y = encoder_parallel(zz, dq, p, "decoder.", cfg["decoder_depth"], cfg["decoder_num_heads"], emu)
     y = output_layer(y, p, emu)                                         # :467
     return unpatchify(y, cfg["temporal_patch_size"], cfg["patch_size"], cfg["token_h"]).contiguous()
 

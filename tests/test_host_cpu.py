@@ -78,7 +78,7 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         vt.make(s)
     s = spec_from_cfg(cfg)
-    s["args"]["train_type"] = "mrope"
+    s["args"]["train_type"] = "rope2d"
     with pytest.raises(NotImplementedError):
         vt.make(s)
     s = spec_from_cfg(cfg)

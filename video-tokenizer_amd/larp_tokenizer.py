@@ -42,14 +42,15 @@ class LARPTokenizer(nn.Module):
                  learned_encoder_patch_pe=False, learned_encoder_latent_query_embed=True, learned_decoder_latent_pe=False,
                  learned_decoder_patch_query_embed=False, use_encoder_patch_token_type_embed=False,
                  use_encoder_latent_query_token_type_embed=False, use_decoder_latent_token_type_embed=False,
-                 use_decoder_patch_query_token_type_embed=False, encoder_query_gaussian_init=True, **ignored):
+                 use_decoder_patch_query_token_type_embed=False, encoder_query_gaussian_init=True, mrope_args=None, **ignored):
         super().__init__()
         # `ignored`: yaml keys the reference class does not take (e.g. use_pe, cfgs/larp_tokenizer.yaml:75)
         if bottleneck_type not in ("vq", "sq", "fsq"):
             raise NotImplementedError(f"bottleneck_type='{bottleneck_type}': this build implements the 'vq', 'sq' and 'fsq' bottlenecks "
                                       "(pass model.args.bottleneck_type vq); 'auto' builds no bottleneck in the reference either")
-        if train_type != "simple":
-            raise NotImplementedError("train_type 'mrope' is out of scope")
+        if train_type not in ("simple", "mrope"):
+            raise NotImplementedError(f"train_type '{train_type}': 'simple' and 'mrope' are built")
+        self.train_type = train_type
         # Options beyond what the fused engine carries (learned / token-type position embeddings, fixed latent queries, a per-frame patch
         # embed, a normalised bottleneck, the 'fsq' branch) run on the COMPOSED path: the same kernels through the sub-modules' own
         # autograd functions, the small embedding sums and the bottleneck LayerNorm as torch glue (forward(): self._composed).
@@ -62,6 +63,7 @@ class LARPTokenizer(nn.Module):
         bn = bottleneck.get("args", {}).get("norm") if isinstance(bottleneck, dict) and bottleneck_type == "vq" else None
         extra["bottleneck_norm"] = bn is not None and str(bn).lower() not in ("no", "none")
         extra["entropy_loss"] = bottleneck_type == "vq" and float(bottleneck["args"]["regularizer"]["args"].get("entropy_loss_weight", 0.0)) > 0
+        extra["train_type_mrope"] = train_type == "mrope"
         self._composed = bottleneck_type == "fsq" or any(extra.values())
         self._composed_why = ", ".join((["bottleneck_type='fsq'"] if bottleneck_type == "fsq" else []) + [k for k, v in extra.items() if v])
         assert temporal_patch_size >= 1
@@ -151,6 +153,17 @@ class LARPTokenizer(nn.Module):
                                                           "head_dim": decoder_hidden_size // decoder_num_heads}}
         self.encoder = registry.make(enc_args)
         self.decoder = registry.make(dec_args)
+        if train_type == "mrope":
+            # larp_tokenizer.py:242-244, 401-405, 459-461: encode / decode go through Encoder111 / Decoder111 (gated layers with 3-axis RoPE,
+            # model_new/base/blocks.py:1110-1178, built with THEIR defaults: 'small' = width 512, a 16x128x128 clip in 4x8x8 patches, 1024
+            # latents -- the tokenizer's hidden size, patching and token count have to agree with that, as in the reference); the plain
+            # encoder / decoder above stay constructed and in the state dict, unused, as they do there.  `mrope_args` (this build only)
+            # overrides those defaults, e.g. for a small test geometry.
+            from .titok import Decoder111, Encoder111
+            ma = dict(mrope_args or {})
+            self.encoder111 = Encoder111(**{k: v for k, v in ma.items() if k in ("model_size", "patch_size", "in_grid", "out_tokens")})
+            self.decoder111 = Decoder111(**{{"in_grid": "out_grid", "out_tokens": "in_tokens"}.get(k, k): v for k, v in ma.items()
+                                            if k in ("model_size", "patch_size", "in_grid", "out_tokens")})
 
         if bottleneck_type == "vq":
             self.bottleneck_dim = bottleneck["args"]["bottleneck_dim"]
@@ -353,11 +366,14 @@ class LARPTokenizer(nn.Module):
         B = x.shape[0]
         nv = (x.shape[2] // self.temporal_patch_size) * (x.shape[3] // self.patch_size) ** 2
         pe = self.get_encoder_patch_pe()[:, :nv]
-        if pe.requires_grad:                      # learned / token-type embeddings: the add carries their gradient
-            tok = self.x_embedder(x) + pe
+        if self.train_type == "mrope":            # :401-405: no additive position embedding, the layers rotate q and k
+            z = self.encoder111(self.x_embedder(x), self.get_encoder_latent_query_embed().expand(B, -1, -1))
         else:
-            tok = self.x_embedder(x, pos_embed=pe[0])
-        z = self.encoder(tok, self.get_encoder_latent_query_embed().expand(B, -1, -1))
+            if pe.requires_grad:                  # learned / token-type embeddings: the add carries their gradient
+                tok = self.x_embedder(x) + pe
+            else:
+                tok = self.x_embedder(x, pos_embed=pe[0])
+            z = self.encoder(tok, self.get_encoder_latent_query_embed().expand(B, -1, -1))
         if self.bottleneck_type == "fsq":
             z = LayerNormRows.apply(z, self.fsq_norm.weight, self.fsq_norm.bias, self.fsq_norm.eps)
             z = Linear.apply(z, self.fsq_in_linear.weight, self.fsq_in_linear.bias)
@@ -389,7 +405,10 @@ class LARPTokenizer(nn.Module):
         B = z.shape[0]
         nv = self.recon_video_token_num if num_x_tokens is None else int(num_x_tokens)
         dq = self.get_decoder_patch_query_embed()[:, :nv]
-        h = self.decoder(z.float() + self.get_decoder_latent_pe(), dq.expand(B, -1, -1))
+        if self.train_type == "mrope":            # :459-461: no latent position embedding either
+            h = self.decoder111(z.float(), dq.expand(B, -1, -1))
+        else:
+            h = self.decoder(z.float() + self.get_decoder_latent_pe(), dq.expand(B, -1, -1))
         fl = self.final_layer
         y = LayerNormRows.apply(h, fl.norm_final.weight, fl.norm_final.bias, fl.norm_final.eps)
         perm = self._head_perm(z.device)

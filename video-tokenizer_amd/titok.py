@@ -351,6 +351,44 @@ class Encoder(nn.Module, _RopeMixin):
         return LinearFn.apply(h[:, :self.out_tokens], self.proj_out.weight, self.proj_out.bias)
 
 
+class Encoder111(nn.Module, _RopeMixin):
+    """blocks.py:1110-1144, the encoder of LARPTokenizer(train_type='mrope'): [latent queries ; patch tokens] through the gated RoPE layer
+    stack, first `out_tokens` rows back.  No projections of its own: the tokenizer's patch embed and bottleneck stay."""
+
+    def __init__(self, model_size="small", patch_size=(4, 8, 8), in_channels=3, out_channels=5, in_grid=(16, 128, 128), out_tokens=1024):
+        super().__init__()
+        self.patch_size, self.token_size, self.in_channels, self.out_tokens = tuple(patch_size), out_channels, in_channels, out_tokens
+        self.grid = [x // y for x, y in zip(in_grid, patch_size)]
+        self.width, self.num_layers, self.heads, mlp_ratio = get_model_dims(model_size)
+        self.freqs = rope_tables(out_tokens, self.grid, head_dim=self.width // self.heads)
+        self._freqs_dev = None
+        self.model_layers = ResidualAttentionBlock(self.width, self.heads, mlp_ratio, self.num_layers)
+        self.apply(init_weights)
+
+    def forward(self, x, query):
+        h = self.model_layers(torch.cat([query.float(), x.float()], dim=1), freqs=self._freqs(x.device))
+        return h[:, :self.out_tokens]
+
+
+class Decoder111(nn.Module, _RopeMixin):
+    """blocks.py:1147-1178: [latents ; patch queries] through the same kind of stack, the rows behind the `in_tokens` latents back"""
+
+    def __init__(self, model_size="small", patch_size=(4, 8, 8), in_tokens=1024, out_grid=(16, 128, 128)):
+        super().__init__()
+        self.patch_size, self.in_tokens = tuple(patch_size), in_tokens
+        self.grid = [x // y for x, y in zip(out_grid, patch_size)]
+        self.grid_size = math.prod(self.grid)
+        self.width, self.num_layers, self.heads, mlp_ratio = get_model_dims(model_size)
+        self.freqs = rope_tables(in_tokens, self.grid, head_dim=self.width // self.heads)
+        self._freqs_dev = None
+        self.model_layers = ResidualAttentionBlock(self.width, self.heads, mlp_ratio, self.num_layers)
+        self.apply(init_weights)
+
+    def forward(self, x, masktoken):
+        h = self.model_layers(torch.cat([x.float(), masktoken.float()], dim=1), freqs=self._freqs(x.device))
+        return h[:, self.in_tokens:]
+
+
 class Decoder(nn.Module, _RopeMixin):
     """blocks.py:85-149: Linear(token_size, width), grid_size scalar mask tokens BEHIND the latents, layers, last grid_size
     rows -> ConvTranspose3d unpatchify"""
