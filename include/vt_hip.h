@@ -115,7 +115,8 @@ typedef struct {
     float* out; int64_t ldo;
     int32_t p_lim, q_lim;
     const int32_t* row_perm;
-    int32_t tile;               /* problem 0's value selects the tile generation of the launch: 0 = automatic, 1 = 128x128, 2 = 192x192 */
+    int32_t tile;               /* problem 0's value selects the tile generation of the launch: 0 = automatic, 1 = 128x128, 2 = 192x192,
+                                   7 = 192x192 without the cross-K-tile register pipeline (round-1 kernel, A/B timing; same bits) */
 } vtGemmTN;
 
 int vt_gemm_tn_grouped(const vtGemmTN* problems_host, int32_t n_problems, vtStream stream);

@@ -71,6 +71,62 @@ def test_from_checkpoint_roundtrip_and_extra_keys(tmp_path):
         vt.LARPTokenizer.from_checkpoint(path, version="bogus")
 
 
+def test_from_pretrained_local_directory_and_public_unpatchify(tmp_path):
+    """larp_tokenizer.py:45 / larp_ar.py:233 (PyTorchModelHubMixin) as called at eval/eval_larp_tokenizer.py:40, sample.py:409,415,
+    trainers/larp_ar_trainer.py:51: `from_pretrained(<local directory>)` reads config.json -> constructor kwargs and model.safetensors ->
+    load_state_dict(strict=True); `save_pretrained` writes that layout.  A directory written by huggingface_hub's OWN mixin (installed
+    here) loads too; a string that is no directory raises instead of reaching for the network.  unpatchify == the einops form (:441-454)."""
+    import einops
+    import json
+    import os
+    from video_tokenizer_amd import larp_ar
+    cfg = O.make_cfg("tiny")
+    spec = spec_from_cfg(cfg)
+    m = vt.make(spec)
+    m.load_state_dict(O.init_state_dict(cfg, seed=3), strict=True)
+    d = m.save_pretrained(str(tmp_path / "tok"))
+    assert sorted(os.listdir(d)) == ["config.json", "model.safetensors"]
+    assert json.load(open(os.path.join(d, "config.json")))["bottleneck_token_num"] == cfg["bottleneck_token_num"]
+    a = vt.LARPTokenizer.from_pretrained(d)
+    assert not a.training and a.bottleneck_token_num == m.bottleneck_token_num
+    for k, v in m.state_dict().items():
+        assert torch.equal(a.state_dict()[k], v), k
+    with pytest.raises(FileNotFoundError, match="never contacts"):
+        vt.LARPTokenizer.from_pretrained("hywang66/LARP-L-long-tokenizer")
+    # the AR prior: constructor takes a dataclass named `config`
+    args = larp_ar.ModelArgs(dim=128, n_layer=2, n_head=2, vocab_size=64, max_seq_len=16, num_classes=5, cls_token_num=1)
+    ar = larp_ar.LARP_AR(args)
+    d2 = ar.save_pretrained(str(tmp_path / "ar"))
+    assert json.load(open(os.path.join(d2, "config.json")))["n_layer"] == 2      # the hub mixin's encoding: the dataclass IS the file
+    b = larp_ar.LARP_AR.from_pretrained(d2)
+    assert b.config == args
+    for k, v in ar.state_dict().items():
+        assert torch.equal(b.state_dict()[k], v), k
+    # a directory in the layout of the hub library itself
+    from huggingface_hub import PyTorchModelHubMixin
+
+    class HubTwin(torch.nn.Module, PyTorchModelHubMixin):
+        def __init__(self, config: larp_ar.ModelArgs):
+            super().__init__()
+            self.inner = larp_ar.LARP_AR(config)
+
+        def state_dict(self, *a, **k):
+            return self.inner.state_dict(*a, **k)
+
+    twin = HubTwin(args)
+    twin.inner.load_state_dict(ar.state_dict())
+    d3 = str(tmp_path / "hub")
+    twin.save_pretrained(d3)
+    c = larp_ar.LARP_AR.from_pretrained(d3)
+    for k, v in ar.state_dict().items():
+        assert torch.equal(c.state_dict()[k], v), k
+    # unpatchify
+    pt, p, hh = m.temporal_patch_size, m.patch_size, m.token_h
+    x = torch.randn(2, m.token_t * hh * hh, pt * p * p * 3)
+    ref = einops.rearrange(x.reshape(-1, m.token_t, hh, hh, pt, p, p, 3), "b t h w pt p1 p2 c -> b c (t pt) (h p1) (w p2)")
+    assert torch.equal(m.unpatchify(x), ref)
+
+
 def test_unsupported_options_fail_loudly():
     cfg = O.make_cfg("tiny")
     s = spec_from_cfg(cfg)
@@ -309,6 +365,20 @@ def test_frechet_distance_and_feature_stats():
     want = ((mu_a - mu_b) ** 2).sum() + np.trace(cov_a) + np.trace(cov_b) - 2 * np.trace(covmean)
     np.testing.assert_allclose(frechet_distance(sa, sb), want, rtol=1e-6)
     assert abs(frechet_distance(sa, sa)) < 1e-6 * np.trace(cov_a)
+    # the eigen-decomposition square root == the SVD form the reference uses (fvd.py:24-33), also on a rank-deficient covariance
+    from video_tokenizer_amd.metrics import psd_sqrt, trace_sqrt_product
+
+    def svd_sqrt(m, eps=1e-10):
+        u, sv, vt_ = torch.linalg.svd(m)
+        return u @ torch.diag(torch.where(sv < eps, sv, sv.sqrt())) @ vt_
+    low = rng.normal(size=(10, 24))
+    for c in (torch.from_numpy(cov_a), torch.from_numpy(cov_b), torch.from_numpy(low.T @ low / 10)):
+        np.testing.assert_allclose(psd_sqrt(c).numpy(), svd_sqrt(c).numpy(), rtol=1e-7, atol=1e-9 * float(c.abs().max()) + 1e-9)
+        other = torch.from_numpy(cov_b)
+        want_tr = torch.trace(svd_sqrt(svd_sqrt(c) @ other @ svd_sqrt(c)))
+        np.testing.assert_allclose(float(trace_sqrt_product(c, other)), float(want_tr), rtol=1e-8)
+    with pytest.raises(ValueError):
+        sa.update(np.zeros((3, 5), dtype=np.float32))
     v = torch.rand(3, 3, 4, 8, 8)
     r = v + 0.1
     mse = clip_mse(v, r)

@@ -251,16 +251,13 @@ def _grads_of(model, x, w, q_weight):
     return out, {n: p.grad.clone() for n, p in model.named_parameters()}
 
 
-def test_config_B_full_size_forward_backward_matches_oracle():
-    """BASELINE configs[1] at its OWN size (cfgs/larp_tokenizer.yaml geometry on 16x128x128 clips: L = 1536, 12 + 12 blocks,
-    d = 24), train(), mode L, forward AND backward against the bf16-emulating CPU oracle that follows the GPU's indices: two clips
-    (M = 3072 = exact 192-row tiles on the persistent walk, compact last-block rows at offsets 512 / 1024, grouped 4-block weight
-    gradients), every parameter gradient (277 tensors).  The oracle takes ~5 s per clip and direction on the box's host cores."""
-    cfg = O.make_cfg("B")
-    model, sd = build(cfg, seed=13)
-    B = 2
-    x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], 81))
-    w = torch.from_numpy(gen.normal(tuple(x.shape), 82))
+def _full_size_forward_backward_parity(name, B, seed, clip_seed):
+    """One config of BASELINE.json at its OWN size, train(), mode L, forward AND backward through the fused engine against the
+    bf16-emulating CPU oracle that follows the GPU's indices: every parameter gradient."""
+    cfg = O.make_cfg(name)
+    model, sd = build(cfg, seed=seed)
+    x = torch.from_numpy(gen.video_clips(B, cfg["frame_num"], cfg["input_size"], clip_seed))
+    w = torch.from_numpy(gen.normal(tuple(x.shape), clip_seed + 1))
     model.train()
     out, grads = _grads_of(model, x.cuda(), w.cuda(), 0.7)
     idx_gpu = out["bottleneck_rep"].cpu()
@@ -289,6 +286,26 @@ def test_config_B_full_size_forward_backward_matches_oracle():
     bad = [(n, rel(grads[n].cpu(), p[n].grad)) for n in grads]
     assert len(bad) == len(list(model.parameters())) and all(p[n].grad is not None for n in grads)
     assert all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:6]
+
+
+def test_config_B_full_size_forward_backward_matches_oracle():
+    """BASELINE configs[1] at its OWN size (cfgs/larp_tokenizer.yaml geometry on 16x128x128 clips: L = 1536, 12 + 12 blocks,
+    d = 24), train(), mode L, forward AND backward against the bf16-emulating CPU oracle that follows the GPU's indices: two clips
+    (M = 3072 = exact 192-row tiles on the persistent walk, compact last-block rows at offsets 512 / 1024, grouped 4-block weight
+    gradients), every parameter gradient (277 tensors).  The oracle takes ~5 s per clip and direction on the box's host cores."""
+    _full_size_forward_backward_parity("B", 2, seed=13, clip_seed=81)
+
+
+@pytest.mark.parametrize("name,B", [("C", 2), ("D", 2), ("E", 1)])
+def test_configs_C_D_E_full_size_forward_backward_match_oracle(name, B):
+    """Round 4 (verdict item): BASELINE configs[2], [3], [4] -- cfgs/larp_tokenizerf256t512.yaml / ...t1024.yaml / larp_tokenizer_large.yaml
+    geometry (pt 4, p 8, 6 + 6 blocks, d = 16; C: 512 latent tokens, L = 1536; D: 1024, L = 2048; E: 16x256x256
+    clips, Nv = 4096, L = 5120) -- at their OWN size with the same bar as config B above: train(), loss sum(pred*w) + 0.7 loss_q,
+    pred_frames / encoded / projected_z 2e-2, every parameter gradient 6e-2, >= 25 % distinct codes, >= 97 % of the free-running
+    indices equal and the others on near ties.  New paths against config B: the d = 16 codebook search / gradient inside
+    vt_tokenizer_backward, Kp = 768 patch rows (pt 4, p 8), compact last-block rows at 1024 / 512 (C), 1024 / 1024 (D), 4096 / 1024 (E),
+    L = 5120 attention (E).  E runs one clip: its oracle holds 12 x 12 x 5120^2 fp32 attention maps for the backward."""
+    _full_size_forward_backward_parity(name, B, seed=17, clip_seed=91)
 
 
 def test_config_B_eight_clips_equal_the_sum_of_single_clip_runs():

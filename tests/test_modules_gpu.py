@@ -405,9 +405,14 @@ def test_lpips_disc_loss_generator_and_discriminator_branches():
         vt.make({"name": "lpips_disc_loss", "args": dict(spec["args"], disc_type="dino")})
     # the SHIPPED spec (cfgs/larp_tokenizer.yaml:120: perceptual_weight 1.0, perceptual_loss 'lpips') constructs and runs: lpips.py is a
     # torch-ops VGG-16 metric with the lpips package's state-dict layout (parity unpinned: the package is not importable here; without
-    # user-supplied weights it warns once and runs on a seeded random init)
+    # user-supplied weights it REFUSES to run -- the reference always trains against the trained metric -- unless VT_LPIPS_ALLOW_RANDOM=1)
+    import os
     import warnings
     lp = vt.make({"name": "lpips_disc_loss", "args": dict(spec["args"], perceptual_weight=1.0)}).cuda()
+    os.environ.pop("VT_LPIPS_ALLOW_RANDOM", None)
+    with pytest.raises(RuntimeError, match="no trained weights"):
+        lp(real.cuda(), fake.detach().cuda(), global_step=10, for_discriminator=False)
+    os.environ["VT_LPIPS_ALLOW_RANDOM"] = "1"
     keys = set(lp.state_dict().keys())
     assert {"perceptual_loss.scaling_layer.shift", "perceptual_loss.net.slice1.0.weight", "perceptual_loss.net.slice5.28.bias",
             "perceptual_loss.lin0.model.1.weight", "perceptual_loss.lins.4.model.1.weight"} <= keys
@@ -427,6 +432,8 @@ def test_lpips_disc_loss_generator_and_discriminator_branches():
     again = LPIPS()
     again.load_state_dict(sd_l, strict=True)                                       # the package's key layout round-trips
     assert again.weights_loaded
+    os.environ.pop("VT_LPIPS_ALLOW_RANDOM", None)
+    again(real[:1, :, 0], fake[:1, :, 0].detach(), normalize=True)                  # loaded weights: runs without the opt-in
 
 
 def test_discriminator_at_the_shipped_size():

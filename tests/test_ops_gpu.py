@@ -177,6 +177,36 @@ def test_gemm_tn_exact_integers_multi_ktile(hip, gemm_variant, M, P, Q):
         assert torch.equal(out.cpu(), dY.t() @ X)
 
 
+@pytest.mark.parametrize("M,P,Q", [(64, 192, 192), (128, 384, 200), (192, 200, 392), (256, 192, 576), (448, 768, 392), (1024, 392, 768)])
+def test_gemm_tn_register_pipeline_is_bit_identical_to_the_burst_kernel(hip, M, P, Q):
+    """Round 4: gemm_tn192p_kernel (fragments of K-tile t+1 read into a second register set while tile t is multiplied, LDS-DMA three
+    tiles ahead) against the round-1 kernel it replaces (vtGemmTN.tile = 7): same MFMA order per accumulator, so the same bits, for
+    1 ... 16 K-tiles (ring wrap-around, both register sets as the last one), ragged P / Q, limits and a row permutation; and exact on
+    small integers (a stale LDS slot or a fragment read before its DMA landed would show)."""
+    g = torch.Generator().manual_seed(M + P)
+    dY = (torch.randn(M, P, generator=g)).to(torch.bfloat16).cuda()
+    X = (torch.randn(M, Q, generator=g)).to(torch.bfloat16).cuda()
+    perm = torch.randperm(P - 8, generator=g).to(torch.int32).cuda()
+    outs = {}
+    for tile in (7, 2):
+        o1 = torch.full((P, Q), -3.0).cuda()
+        o2 = torch.full((P, Q), -3.0).cuda()
+        hip.gemm_tn_grouped([dict(A=dY, B=X, out=o1, tile=tile), dict(A=dY, B=X, out=o2, p_lim=P - 8, q_lim=Q - 8, row_perm=perm, tile=tile)])
+        torch.cuda.synchronize()
+        outs[tile] = (o1, o2)
+    assert torch.equal(outs[7][0], outs[2][0]) and torch.equal(outs[7][1], outs[2][1])
+    ref = dY.float().t() @ X.float()
+    assert (outs[2][0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert torch.all(outs[2][1][P - 8:] == -3.0) and torch.all(outs[2][1][:, Q - 8:] == -3.0)
+    di = torch.randint(-3, 4, (M, P), generator=g).float()
+    xi = torch.randint(-3, 4, (M, Q), generator=g).float()
+    for _ in range(2):
+        o = torch.zeros(P, Q).cuda()
+        hip.gemm_tn_grouped([dict(A=di.to(torch.bfloat16).cuda(), B=xi.to(torch.bfloat16).cuda(), out=o, tile=2)])
+        torch.cuda.synchronize()
+        assert torch.equal(o.cpu(), di.t() @ xi)
+
+
 def test_gemm_tn_exact_integers(hip, gemm_variant):
     M, P, Q = 128, 128, 128
     dY = ((torch.arange(M).reshape(M, 1) * 5 + torch.arange(P).reshape(1, P) * 3) % 9).float()
@@ -538,7 +568,7 @@ def test_vq_forward_bit_exact_vs_c_oracle(hip, case, mode, golden_dir):
     assert np.array_equal(o["idx"].cpu().numpy(), f["idx"].reshape(-1).astype(np.int64))
 
 
-@pytest.mark.parametrize("case", vq_cases()[:2])
+@pytest.mark.parametrize("case", vq_cases())    # all three fixtures: d = 24 twice and the d = 16 one (configs C / D / E)
 def test_vq_backward_matches_reference_grads(hip, case, golden_dir):
     (b, n), K, d, seed = case
     f = np.load(f"{golden_dir}/vq_N{b * n}_K{K}_d{d}_L.npz")

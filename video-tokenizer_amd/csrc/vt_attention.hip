@@ -29,13 +29,40 @@
 
 #include "vt_attn_tile.h"
 
+// Diagnostic build only (-DVT_ATTN_STAMPS, tools/attn_stamps.sh): s_memtime stamps around the three segments of a tile iteration
+// (tile body = staging issue + MFMA / softmax | s_waitcnt vmcnt(0) on the next tile's LDS-DMA | workgroup barrier), summed per wave.
+// The shares are what to read, never the run time (cdna_hip_programming.md section 7, "In-kernel stamps").
+#ifdef VT_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[3][2048][4][4];     // [kernel: fwd, dq, dkv][workgroup][wave][body, drain, barrier, iterations]
+#define VT_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[4] = {0, 0, 0, 0}
+#define VT_STAMP(i)                                                      \
+    {                                                                    \
+        const unsigned long long st_n = __builtin_amdgcn_s_memtime();    \
+        st_acc[i] += st_n - st_t;                                        \
+        st_t = st_n;                                                     \
+    }
+#define VT_STAMP_ITER st_acc[3] += 1
+#define VT_STAMP_START st_t = __builtin_amdgcn_s_memtime()
+#define VT_STAMP_FLUSH(kern)                                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                                              \
+        for (int i_ = 0; i_ < 4; ++i_) g_attn_stamps[kern][blockIdx.x][threadIdx.x >> 6][i_] = st_acc[i_]
+#else
+#define VT_STAMP_DECL
+#define VT_STAMP(i)
+#define VT_STAMP_ITER
+#define VT_STAMP_START
+#define VT_STAMP_FLUSH(kern)
+#endif
+
 namespace {
 
 // one 64-key tile of the forward: S^T = K.Q^T, online softmax (log2 domain; max taken on the raw scores since
 // the scale is positive), O^T += V^T.P^T.  TAIL masks keys >= L (last tile of a ragged sequence only).
+// Round 4: fragments from precomputed lane offsets + immediates (TileAddr), and the softmax arithmetic two elements per
+// instruction (v_pk_fma_f32 for s * c - m, v_pk_add_f32 for the row sum): 11.6 -> ~7 vector instructions per MFMA.
 template <int HD, bool TAIL>
-__device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const bf16x8 (&qf)[HD / 16], f32x16 (&oacc)[HD / 32], float& m, float& lsum,
-                                         int key0, int L, float c, int lane, int half) {
+__device__ __forceinline__ void fwd_tile(unsigned kl, unsigned vl, const TileAddr<HD>& ad, const bf16x8 (&qf)[HD / 16], f32x16 (&oacc)[HD / 32],
+                                         float& m, float& lsum, int key0, int L, float c, int half) {
     f32x16 sacc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -43,7 +70,7 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
         for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s)
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(kl, kt * 32, s, lane), qf[s], sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag_a<HD>(kl, ad, kt * 32, s), qf[s], sacc[kt], 0, 0, 0);
     }
     float mx = -__builtin_inff();
 #pragma unroll
@@ -69,17 +96,20 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
     }
-    const float mn = m;
-    float ps = 0.f;
+    const f32x2 c2 = {c, c}, nm2 = {-m, -m};
+    f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c, -mn));
-            sacc[kt][r] = p;
-            ps += p;
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 sv = {sacc[kt][r], sacc[kt][r + 1]};
+            const f32x2 t = __builtin_elementwise_fma(sv, c2, nm2);
+            const f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            ps2 += pv;
+            sacc[kt][r] = pv[0];
+            sacc[kt][r + 1] = pv[1];
         }
-    lsum += ps;
+    lsum += ps2[0] + ps2[1];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -87,7 +117,7 @@ __device__ __forceinline__ void fwd_tile(const char* kl, const char* vl, const b
             const bf16x8 pf = pack8(sacc[kt], sp);
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt)
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(vl, kt * 32, sp, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_a<HD>(vl, ad, kt * 32, sp, dt), pf, oacc[dt], 0, 0, 0);
         }
 }
 
@@ -132,6 +162,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 3 : 4) void attn_fwd_kernel(const bf1
     const int nt = (L + 63) / 64;
     // LDS: [buffer 0: K | V][buffer 1: K | V]
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const TileAddr<HD> ad = tile_addr<HD>(lane, sbase);
     stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
     stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
     pin_loaded(qf);
@@ -160,15 +191,15 @@ __global__ __launch_bounds__(256, CAUSAL ? 3 : 4) void attn_fwd_kernel(const bf1
                     stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
                 }
             }
-            const char* kl = smem + cur * 2 * TILE;
-            if (t < nvis) fwd_tile<HD, false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
-            else if (t * 64 <= q0 + 31) fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, lim, scale_log2e, lane, half);
+            const unsigned kl = cur * 2 * TILE;
+            if (t < nvis) fwd_tile<HD, false>(kl, kl + TILE, ad, qf, oacc, m, lsum, t * 64, L, scale_log2e, half);
+            else if (t * 64 <= q0 + 31) fwd_tile<HD, true>(kl, kl + TILE, ad, qf, oacc, m, lsum, t * 64, lim, scale_log2e, half);
             dma_drain();
             __syncthreads();
         }
     } else {
-    for (int t = 0; t < nfull; ++t) {
-        const int cur = t & 1;
+    // two tiles per trip so that the LDS buffer of a tile body is a compile-time constant (an instruction immediate, not an add)
+    auto stage_next = [&](int t, int cur) {   // tile t + 1 into the other buffer
         if (t + 1 < nfull) {          // next tile is a full one: scalar base + invariant lane offsets
             const bf16_t* kt = kb + (int64_t)(t + 1) * 64 * rs;
             stage64_full<HD>(kt, soff, sbase + (cur ^ 1) * 2 * TILE, wave);
@@ -177,14 +208,33 @@ __global__ __launch_bounds__(256, CAUSAL ? 3 : 4) void attn_fwd_kernel(const bf1
             stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
             stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
-        const char* kl = smem + cur * 2 * TILE;
-        fwd_tile<HD, false>(kl, kl + TILE, qf, oacc, m, lsum, t * 64, L, scale_log2e, lane, half);
+    };
+    VT_STAMP_DECL;
+    for (int t = 0; t < nfull; t += 2) {
+        VT_STAMP_START;
+        stage_next(t, 0);
+        fwd_tile<HD, false>(0, TILE, ad, qf, oacc, m, lsum, t * 64, L, scale_log2e, half);
+        VT_STAMP(0);
         dma_drain();
+        VT_STAMP(1);
         __syncthreads();
+        VT_STAMP(2);
+        VT_STAMP_ITER;
+        if (t + 1 < nfull) {
+            stage_next(t + 1, 1);
+            fwd_tile<HD, false>(2 * TILE, 3 * TILE, ad, qf, oacc, m, lsum, (t + 1) * 64, L, scale_log2e, half);
+            VT_STAMP(0);
+            dma_drain();
+            VT_STAMP(1);
+            __syncthreads();
+            VT_STAMP(2);
+            VT_STAMP_ITER;
+        }
     }
+    VT_STAMP_FLUSH(0);
     if (nfull < nt) {
-        const char* kl = smem + (nfull & 1) * 2 * TILE;
-        fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane, half);
+        const unsigned kl = (nfull & 1) * 2 * TILE;
+        fwd_tile<HD, true>(kl, kl + TILE, ad, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, half);
     }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32);
@@ -194,341 +244,10 @@ __global__ __launch_bounds__(256, CAUSAL ? 3 : 4) void attn_fwd_kernel(const bf1
     if (ok && half == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);  // v_log_f32 = log2
 }
 
-// ------------------------------------------------------------------------------------------------
-// forward, software-pipelined inside the wave (head_dim 64)
-//
-// The plain kernel above runs S = K.Q^T, the softmax and O += V^T.P one after the other, so a wave's matrix instructions
-// and its vector instructions never overlap (PMC, round 1: matrix pipe 27 % busy + vector issue 55 % of the kernel, the
-// SUM of the two was the run time; co-resident waves did not fill the gaps).  Here the unit of work is a 32-key HALF tile
-// and every iteration v issues, in program order,
-//     4 MFMAs  S(v+1) = K_half(v+1) . Q^T        (scores of the NEXT half)
-//     4 MFMAs  O^T   += V_half(v-1)^T . P(v-1)   (accumulate the PREVIOUS half)
-// with the 16 exponentials / row sums / bf16 packs of half v -- which depend on neither -- placed between them, two
-// elements per MFMA, in source order fenced by sched_barrier(0).  An MFMA keeps the SIMD's vector issue for 8 of its 32
-// cycles, so ~6 vector instructions ride in its shadow.
-//
-// LDS ring: K and V each two 64-key buffers.  Iteration 2t reads K(t) rows 32..63 and V(t-1) rows 32..63; iteration
-// 2t+1 reads K(t+1) rows 0..31 and V(t) rows 0..31, and issues the DMA of K(t+2) -> K buffer t&1 and V(t+1) -> V buffer
-// (t+1)&1, both last read in iteration 2t: ONE vmcnt(0) + barrier per 64 keys, after the even iteration.
-//
-// Lazy rescaling with a pipeline: the decision for half v+1 is taken at the end of iteration v (its scores are ready),
-// the new reference point is used for the exponentials of v+1, and O / l -- which by then also hold half v, exponentiated
-// at the OLD reference -- are multiplied by alpha at the end of iteration v+1 ("scale everything still at the old
-// reference exactly once").  A ragged last tile is not pipelined: fwd_tile<TAIL> after the loop.
-// ------------------------------------------------------------------------------------------------
-// max / sum of a value with its partner lane (lane ^ 32) without an index register or an LDS round trip:
-// v_permlane32_swap exchanges lanes 32..63 of the first operand with lanes 0..31 of the second
-__device__ __forceinline__ float xhalf_max(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-
-struct FwdState {
-    float m;          // reference point of the exponentials (log2 domain), per query = per lane
-    float lsum;       // row sum at the scale O is at
-    float alpha_p;    // pending multiplier for O / lsum
-    bool pend;        // wave-uniform
-};
-
-// Per-lane LDS byte offsets of the fragments, relative to a tile image: everything that depends on the buffer, the 32-row
-// half or the k-step is a compile-time constant added on top (the swizzle f(row) has period 8 rows), so it lands in the
-// instruction's offset field and the loop carries 8 address registers instead of ~50 hoisted address computations.
-struct PipeAddr {
-    unsigned k[4];       // K row fragment of k-step s: row lane&31
-    unsigned v[2][2];    // V transposed fragment, [dt][rows +0 / +8]
-};
-__device__ __forceinline__ PipeAddr pipe_addr(int lane) {
-    PipeAddr a;
-    const int row = lane & 31, hf = lane >> 5;
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) a.k[s_] = row * 128 + (((2 * s_ + hf) ^ fsw<64>(row)) << 4);
-    const int g = lane >> 4, lam = lane & 15;
-    const int r0 = 4 * (g >> 1) + (lam >> 2), r1 = r0 + 8;
-    const int bo = (lam & 1) << 3;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const int lc = ((dt * 32 + 16 * (g & 1)) >> 3) + ((lam & 3) >> 1);
-        a.v[dt][0] = r0 * 128 + ((lc ^ fsw<64>(r0)) << 4) + bo;
-        a.v[dt][1] = r1 * 128 + ((lc ^ fsw<64>(r1)) << 4) + bo;
-    }
-    return a;
-}
-constexpr int PIPE_TILE = 64 * 128;   // bytes of a [64][64] bf16 tile; LDS = [K0][V0][K1][V1]
-// `pa.k` point into the K buffer in use, `pa.v` into the V buffer in use (the buffer base is part of the register: the
-// kernel flips it with one XOR per address and tile); R0 = first row of the 32-row half, a compile-time constant
-template <int R0>
-__device__ __forceinline__ bf16x8 pipe_kfrag(const char* smem, const PipeAddr& pa, int s_) {
-    return *(const bf16x8*)(smem + pa.k[s_] + R0 * 128);
-}
-template <int R0>
-__device__ __forceinline__ bf16x8 pipe_vfrag(const char* smem, const PipeAddr& pa, int i) {   // i = 2 * sp + dt
-    const int sp = i >> 1, dt = i & 1;
-    const int cst = PIPE_TILE + (R0 + 16 * sp) * 128;
-    return cat4(lds_read_tr16(smem + pa.v[dt][0] + cst), lds_read_tr16(smem + pa.v[dt][1] + cst));
-}
-
-// one iteration: S_next = K rows [KR, KR+32) . Q^T (if QK), O += V rows [VR, VR+32) . p_prev (if PV), and the softmax of
-// s_cur -> p_cur (bf16 B fragments of the two 16-key k-steps), row sum into lsum
-// DBG (timing ablations, WRONG results; tools/attn_ablate.sh): 1 no exponentials, 2 no S MFMAs, 4 no PV MFMAs, 8 no LDS fragment
-// reads, 16 no softmax arithmetic at all
-template <bool QK, bool PV, int KR, int VR, int DBG = 0>
-__device__ __forceinline__ void fwd_pipe_iter(const char* smem, const PipeAddr& ad, const bf16x8 (&qf)[4], f32x16& s_next, f32x16& s_cur,
-                                              bf16x8 (&p)[2], f32x16 (&oacc)[2], FwdState& st, float c) {
-    // p: on entry the packed P of the previous half (B operands of the PV MFMAs), on exit those of this half.  Each k-step
-    // is re-packed right behind the last MFMA that reads the old one, so P never needs a second register set.
-    // Fragments are read two MFMAs ahead of their use into rotating registers.  hipcc is free to move pure arithmetic and
-    // MFMAs anywhere (it SINKS the softmax below the rescale branch and clusters the MFMAs when left alone), so the
-    // interleave is pinned by empty asm statements: PIN_F(frag) in front of an MFMA makes the MFMA wait for that point,
-    // PIN_P after a pair of exponentials keeps them above it; asm volatile statements keep their relative order.
-    bf16x8 fa, fb, fc, fd;
-#define VT_PIN_F(f) asm volatile("" : "+v"(f))
-    if (QK) { fa = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 0)); fb = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 1)); }
-    else if (PV) { fc = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 0)); fd = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 1)); }
-    // The kernel is bound by vector ISSUE (PMC: SQ_ACTIVE_INST_VALU 74 % of the kernel, one quad-cycle per plain VALU
-    // instruction and two per v_exp_f32, whatever the number of resident waves), so the arithmetic around the exponentials
-    // is done two elements per instruction: v_pk_fma_f32 for s * c - m, v_pk_add_f32 for the row sum.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 nm2 = {-st.m, -st.m}, c2 = {c, c};
-    f32x2 ps2 = {0.f, 0.f};
-#define VT_SM2(r)                                                            \
-    if (!(DBG & 16)) {                                                       \
-        const f32x2 sv = {s_cur[r], s_cur[(r) + 1]};                         \
-        const f32x2 t = __builtin_elementwise_fma(sv, c2, nm2);              \
-        f32x2 pv = {(DBG & 1) ? t[0] : __builtin_amdgcn_exp2f(t[0]), (DBG & 1) ? t[1] : __builtin_amdgcn_exp2f(t[1])}; \
-        ps2 += pv;                                                           \
-        asm volatile("" : "+v"(pv), "+v"(ps2));                              \
-        s_cur[r] = pv[0];                                                    \
-        s_cur[(r) + 1] = pv[1];                                              \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-    }
-    if (QK) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
-        VT_PIN_F(fa);
-        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qf[0], s_next, 0, 0, 0);
-        fa = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 2));
-    }
-    VT_SM2(0);
-    if (QK) {
-        VT_PIN_F(fb);
-        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, qf[1], s_next, 0, 0, 0);
-        fb = ((DBG & 8) ? qf[0] : pipe_kfrag<KR>(smem, ad, 3));
-    }
-    VT_SM2(2);
-    if (QK) {
-        VT_PIN_F(fa);
-        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, qf[2], s_next, 0, 0, 0);
-        if (PV) fc = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 0));
-    }
-    VT_SM2(4);
-    if (QK) {
-        VT_PIN_F(fb);
-        if (!(DBG & 2)) s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, qf[3], s_next, 0, 0, 0);
-        if (PV) fd = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 1));
-    }
-    VT_SM2(6);
-    if (PV) {
-        VT_PIN_F(fc);
-        if (!(DBG & 4)) oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc, p[0], oacc[0], 0, 0, 0);
-        fc = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 2));
-    }
-    VT_SM2(8);
-    if (PV) {
-        VT_PIN_F(fd);
-        if (!(DBG & 4)) oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, p[0], oacc[1], 0, 0, 0);
-        fd = ((DBG & 8) ? qf[1] : pipe_vfrag<VR>(smem, ad, 3));
-    }
-    p[0] = pack8(s_cur, 0);
-    VT_SM2(10);
-    if (PV) {
-        VT_PIN_F(fc);
-        if (!(DBG & 4)) oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc, p[1], oacc[0], 0, 0, 0);
-    }
-    VT_SM2(12);
-    if (PV) {
-        VT_PIN_F(fd);
-        if (!(DBG & 4)) oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, p[1], oacc[1], 0, 0, 0);
-    }
-    VT_SM2(14);
-    p[1] = pack8(s_cur, 1);
-#undef VT_SM2
-#undef VT_PIN_F
-    // O and lsum now hold half v-1 too: bring them to the reference the exponentials above used
-    if (st.pend) {
-        const float a = st.alpha_p;
-        st.lsum *= a;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= a;
-        st.pend = false;
-    }
-    st.lsum += ps2[0] + ps2[1];
-    if (QK) {   // decision for the half whose scores just arrived
-        float mx = fmaxf(s_next[0], s_next[1]);
-#pragma unroll
-        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s_next[r]);
-        mx = xhalf_max(mx);
-        const float want = mx * c;
-        if (__builtin_amdgcn_ballot_w64(want > st.m + 8.0f) != 0ull) {
-            const float mn = fmaxf(st.m, want);
-            st.alpha_p = __builtin_amdgcn_exp2f(st.m - mn);
-            st.m = mn;
-            st.pend = true;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the next iteration's reads / MFMAs stay behind this one (register pressure)
-}
-
-// NW waves per workgroup (4 or 8), 32 queries each: 8 waves share one K/V stream, which halves the L2 -> LDS traffic per query
-template <int DBG, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse2,
-                                                                int L, int H, int nblk, float scale_log2e, int q_begin) {
-    constexpr int HD = 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5;
-    const int sid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = sid / nblk, blk = sid - bh * nblk;
-    const int b = bh / H, h = bh % H;
-    const int64_t rs = (int64_t)3 * H * HD;
-    const bf16_t* qb = qkv + (int64_t)b * L * rs + (int64_t)h * HD;
-    const bf16_t* kb = qb + (int64_t)H * HD;
-    const bf16_t* vb = kb + (int64_t)H * HD;
-    const int q0 = q_begin + blk * (32 * NW) + wave * 32;
-    const int Lq = L - q_begin;
-
-    constexpr int TILE = AG<HD>::TILE;
-    static_assert(TILE == PIPE_TILE, "tile image size");
-    bf16x8 qf[4];
-    load_own<4>(qb, rs, q0, L, lane, qf);
-    f32x16 oacc[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-
-    const int nt = (L + 63) / 64;
-    const int nfull = L / 64;                 // tiles the pipeline handles; a ragged last tile (nt == nfull + 1) runs after it
-    // LDS: [K buffer 0][V buffer 0][K buffer 1][V buffer 1]
-    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    constexpr int NTH = 64 * NW, PIECES = 512 / NTH;   // 16-B DMA pieces per thread and tile
-    unsigned soff[PIECES];
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int slot = i * NTH + tid, row = slot >> 3;
-        soff[i] = (unsigned)((row * rs + (((slot & 7) ^ fsw<HD>(row)) << 3)) * 2);
-    }
-    auto stage_full = [&](const bf16_t* tile_row0, unsigned lds) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) glds16_sv(tile_row0, soff[i], lds + (i * NTH + wave * 64) * 16);
-    };
-    auto stage_clamped = [&](const bf16_t* src, int row0, unsigned lds) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int slot = i * NTH + tid, row = slot >> 3;
-            int gr = row0 + row;
-            gr = gr < L ? gr : L - 1;
-            glds16_asm(src + (int64_t)gr * rs + (((slot & 7) ^ fsw<HD>(row)) << 3), lds + (i * NTH + wave * 64) * 16);
-        }
-    };
-    // full tiles only inside the pipeline (scalar base + invariant lane offsets); the ragged last tile, if any, is staged
-    // with clamped rows after the loop -- its 64-bit per-lane address arithmetic would otherwise live in the hot loop
-    auto stage_k = [&](int t) { stage_full(kb + (int64_t)t * 64 * rs, sbase + (t & 1) * 2 * TILE); };
-    auto stage_v = [&](int t) { stage_full(vb + (int64_t)t * 64 * rs, sbase + (t & 1) * 2 * TILE + TILE); };
-    if (nfull > 0) {
-        stage_k(0);
-        stage_v(0);
-        if (nfull > 1) stage_k(1);
-    } else {
-        stage_clamped(kb, 0, sbase);
-        stage_clamped(vb, 0, sbase + TILE);
-    }
-    pin_loaded(qf);
-    dma_drain();
-    __syncthreads();
-
-    FwdState st;
-    st.m = -__builtin_inff();
-    st.lsum = 0.f;
-    st.alpha_p = 1.f;
-    st.pend = false;
-    const float c = scale_log2e;
-    if (nfull > 0) {
-        PipeAddr ad = pipe_addr(lane);      // K addresses -> K buffer 0, V addresses -> V buffer 0
-        f32x16 sa, sb;                      // scores of the current / next half (they swap roles every iteration)
-        bf16x8 pk[2];
-        {   // S(0) and its reference point
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sa[r] = 0.f;
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pipe_kfrag<0>(smem, ad, s_), qf[s_], sa, 0, 0, 0);
-            float mx = fmaxf(sa[0], sa[1]);
-#pragma unroll
-            for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sa[r]);
-            mx = xhalf_max(mx);
-            st.m = mx * c;
-        }
-        // iteration 0 (tile 0, second half of K): nothing to accumulate yet
-        fwd_pipe_iter<true, false, 32, 32, DBG>(smem, ad, qf, sb, sa, pk, oacc, st, c);
-        dma_drain();
-        __syncthreads();
-        // one trip per tile t: odd iteration 2t+1 (scores sb, previous P pa; K(t+1) rows 0.., V(t) rows 0..), then even
-        // iteration 2t+2 (scores sa, previous P pb; K(t+1) rows 32.., V(t) rows 32..).  K addresses point at buffer
-        // (t+1)&1, V addresses at buffer t&1: both flip at the end of the trip.
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) ad.k[s_] ^= 2 * PIPE_TILE;
-        for (int t = 0; t + 1 < nfull; ++t) {
-            if (t + 2 < nfull) stage_k(t + 2);
-            stage_v(t + 1);
-            fwd_pipe_iter<true, true, 0, 0, DBG>(smem, ad, qf, sa, sb, pk, oacc, st, c);
-            fwd_pipe_iter<true, true, 32, 32, DBG>(smem, ad, qf, sb, sa, pk, oacc, st, c);
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) ad.k[s_] ^= 2 * PIPE_TILE;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                ad.v[dt][0] ^= 2 * PIPE_TILE;
-                ad.v[dt][1] ^= 2 * PIPE_TILE;
-            }
-            dma_drain();
-            __syncthreads();
-        }
-        {   // last full tile (t = nfull - 1): no further scores; accumulate both of its halves and leave the pipeline
-            if (nfull < nt) {   // the ragged tile: both of its buffers were last read before the loop's final barrier
-                stage_clamped(kb, nfull * 64, sbase + (nfull & 1) * 2 * TILE);
-                stage_clamped(vb, nfull * 64, sbase + (nfull & 1) * 2 * TILE + TILE);
-            }
-            fwd_pipe_iter<false, true, 0, 0, DBG>(smem, ad, qf, sa, sb, pk, oacc, st, c);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                oacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pipe_vfrag<32>(smem, ad, i), pk[i >> 1], oacc[i & 1], 0, 0, 0);
-        }
-    }
-    float m = st.m, lsum = st.lsum;
-    // Everything the epilogue needs is recomputed from an opaque copy of the thread index: values kept live across the tile
-    // loop only for these few stores cost registers the loop has no room for (they were spilled to scratch otherwise).
-    int tid2 = threadIdx.x;
-    asm volatile("" : "+v"(tid2));
-    const int lane2 = tid2 & 63, half2 = lane2 >> 5;
-    if (nfull < nt) {
-        if (nfull > 0) {        // K(nfull) / V(nfull) were issued inside the loop (or the prologue): make them visible
-            dma_drain();
-            __syncthreads();
-        }
-        const char* kl = smem + (nfull & 1) * 2 * TILE;
-        fwd_tile<HD, true>(kl, kl + TILE, qf, oacc, m, lsum, nfull * 64, L, scale_log2e, lane2, half2);
-    }
-    const float ltot = lsum + __shfl_xor(lsum, 32);
-    const int q = q_begin + blk * (32 * NW) + (tid2 >> 6) * 32 + (lane2 & 31);
-    const bool ok = q < L;
-    store_own<2>(oacc, 1.0f / ltot, o + (int64_t)b * Lq * H * HD + (int64_t)h * HD, (int64_t)H * HD, q - q_begin, ok, half2);
-    if (ok && half2 == 0) lse2[((int64_t)b * H + h) * L + q] = m + __builtin_amdgcn_logf(ltot);
-}
-
 template <int HD, bool TAIL>
-__device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf16x8 (&qf)[HD / 16], const bf16x8 (&dof)[HD / 16], f32x16 (&dq)[HD / 32],
-                                        float my_lse, float my_delta, int key0, int L, float c, int lane, int half) {
+__device__ __forceinline__ void dq_tile(unsigned kl, unsigned vl, const TileAddr<HD>& ad, const bf16x8 (&qf)[HD / 16], const bf16x8 (&dof)[HD / 16],
+                                        f32x16 (&dq)[HD / 32], float my_lse, float my_delta, int key0, int L, float c, int half) {
+    const f32x2 c2 = {c, c}, nl2 = {-my_lse, -my_lse}, nd2 = {-my_delta, -my_delta};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         f32x16 sacc, dp;
@@ -536,21 +255,27 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
         for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(kl, kt * 32, s, lane), qf[s], sacc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(vl, kt * 32, s, lane), dof[s], dp, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag_a<HD>(kl, ad, kt * 32, s), qf[s], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag_a<HD>(vl, ad, kt * 32, s), dof[s], dp, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -my_lse));
-            if (TAIL && (key0 + kt * 32 + reg_row(r, half) >= L)) p = 0.f;
-            sacc[r] = p * (dp[r] - my_delta);  // dS (unscaled)
+        for (int r = 0; r < 16; r += 2) {   // two elements per instruction: v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32
+            const f32x2 t = __builtin_elementwise_fma((f32x2){sacc[r], sacc[r + 1]}, c2, nl2);
+            f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            if (TAIL) {
+                if (key0 + kt * 32 + reg_row(r, half) >= L) p[0] = 0.f;
+                if (key0 + kt * 32 + reg_row(r + 1, half) >= L) p[1] = 0.f;
+            }
+            const f32x2 ds = p * ((f32x2){dp[r], dp[r + 1]} + nd2);  // dS (unscaled)
+            sacc[r] = ds[0];
+            sacc[r + 1] = ds[1];
         }
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             const bf16x8 dsf = pack8(sacc, sp);
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(kl, kt * 32, sp, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_a<HD>(kl, ad, kt * 32, sp, dt), dsf, dq[dt], 0, 0, 0);
         }
     }
 }
@@ -561,7 +286,7 @@ __device__ __forceinline__ void dq_tile(const char* kl, const char* vl, const bf
 // leaves it in `delta` for the dK/dV kernel, which is launched behind this one.
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool CAUSAL = false>
-__global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ dO, const float* __restrict__ lse2,
                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, int H, int nblk,
                                                               float scale, float scale_log2e, int q_begin) {
@@ -607,6 +332,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dq_kernel(const 
     const int nt = (L + 63) / 64;
     // LDS: [buffer 0: K | V][buffer 1: K | V]
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const TileAddr<HD> ad = tile_addr<HD>(lane, sbase);
     stage64<HD>(kb, rs, 0, L, sbase, tid, wave);
     stage64<HD>(vb, rs, 0, L, sbase + TILE, tid, wave);
     pin_loaded(qf);
@@ -637,15 +363,14 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dq_kernel(const 
                     stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
                 }
             }
-            const char* kl = smem + cur * 2 * TILE;
-            if (t < nvis) dq_tile<HD, false>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, t * 64, L, scale_log2e, lane, half);
-            else if (t * 64 <= q0 + 31) dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, t * 64, lim, scale_log2e, lane, half);
+            const unsigned kl = cur * 2 * TILE;
+            if (t < nvis) dq_tile<HD, false>(kl, kl + TILE, ad, qf, dof, dq, lse_pin, my_delta, t * 64, L, scale_log2e, half);
+            else if (t * 64 <= q0 + 31) dq_tile<HD, true>(kl, kl + TILE, ad, qf, dof, dq, lse_pin, my_delta, t * 64, lim, scale_log2e, half);
             dma_drain();
             __syncthreads();
         }
     } else {
-    for (int t = 0; t < nfull; ++t) {
-        const int cur = t & 1;
+    auto stage_next = [&](int t, int cur) {   // tile t + 1 into the other buffer
         if (t + 1 < nfull) {
             const bf16_t* kt = kb + (int64_t)(t + 1) * 64 * rs;
             stage64_full<HD>(kt, soff, sbase + (cur ^ 1) * 2 * TILE, wave);
@@ -654,14 +379,33 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dq_kernel(const 
             stage64<HD>(kb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE, tid, wave);
             stage64<HD>(vb, rs, (t + 1) * 64, L, sbase + (cur ^ 1) * 2 * TILE + TILE, tid, wave);
         }
-        const char* kl = smem + cur * 2 * TILE;
-        dq_tile<HD, false>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, t * 64, L, scale_log2e, lane, half);
+    };
+    VT_STAMP_DECL;
+    for (int t = 0; t < nfull; t += 2) {      // two tiles per trip: the LDS buffer of a body is an instruction immediate
+        VT_STAMP_START;
+        stage_next(t, 0);
+        dq_tile<HD, false>(0, TILE, ad, qf, dof, dq, lse_pin, my_delta, t * 64, L, scale_log2e, half);
+        VT_STAMP(0);
         dma_drain();
+        VT_STAMP(1);
         __syncthreads();
+        VT_STAMP(2);
+        VT_STAMP_ITER;
+        if (t + 1 < nfull) {
+            stage_next(t + 1, 1);
+            dq_tile<HD, false>(2 * TILE, 3 * TILE, ad, qf, dof, dq, lse_pin, my_delta, (t + 1) * 64, L, scale_log2e, half);
+            VT_STAMP(0);
+            dma_drain();
+            VT_STAMP(1);
+            __syncthreads();
+            VT_STAMP(2);
+            VT_STAMP_ITER;
+        }
     }
+    VT_STAMP_FLUSH(1);
     if (nfull < nt) {
-        const char* kl = smem + (nfull & 1) * 2 * TILE;
-        dq_tile<HD, true>(kl, kl + TILE, qf, dof, dq, lse_pin, my_delta, nfull * 64, L, scale_log2e, lane, half);
+        const unsigned kl = (nfull & 1) * 2 * TILE;
+        dq_tile<HD, true>(kl, kl + TILE, ad, qf, dof, dq, lse_pin, my_delta, nfull * 64, L, scale_log2e, half);
     }
     }
     store_own<DT>(dq, scale, dqkv + (int64_t)b * L * rs + (int64_t)h * HD, rs, q, q < L, half);
@@ -669,12 +413,12 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dq_kernel(const 
 
 // one 64-query tile of the dK/dV sweep.  LDS buffer: Q tile | dO tile | lse2[64] | delta[64]
 template <int HD, bool TAIL, bool CAUSAL = false>
-__device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD / 16], const bf16x8 (&vf)[HD / 16], f32x16 (&dk)[HD / 32],
-                                         f32x16 (&dv)[HD / 32], int q0, int L, float c, int lane, int half, int my_key = 0) {
+__device__ __forceinline__ void dkv_tile(unsigned qt_l, unsigned lse_a, const TileAddr<HD>& ad, const bf16x8 (&kf)[HD / 16], const bf16x8 (&vf)[HD / 16],
+                                         f32x16 (&dk)[HD / 32], f32x16 (&dv)[HD / 32], int q0, int L, float c, int half, int my_key = 0) {
     constexpr int TILE = AG<HD>::TILE;
-    const char* do_l = qt_l + TILE;
-    const float* lse_l = (const float*)(qt_l + 2 * TILE);
-    const float* del_l = lse_l + 64;
+    const unsigned do_l = qt_l + TILE;
+    const unsigned lse_l = lse_a + qt_l + 2 * TILE;      // lse_a = LDS base + 16 * half: this lane's 16 query rows are 4 runs of 4 consecutive rows, qt*32 + 8g + 4*half + 0..3
+    const f32x2 nc2 = {-c, -c};
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         f32x16 sacc, dp;
@@ -682,22 +426,33 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD
         for (int r = 0; r < 16; ++r) sacc[r] = dp[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(qt_l, qt * 32, s, lane), kf[s], sacc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag<HD>(do_l, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag_a<HD>(qt_l, ad, qt * 32, s), kf[s], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag_a<HD>(do_l, ad, qt * 32, s), vf[s], dp, 0, 0, 0);
         }
-        // this lane's 16 query rows are 4 runs of 4 consecutive rows: rows qt*32 + 8g + 4*half + 0..3
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 lse4 = *(const f32x4*)(lse_l + qt * 32 + 8 * g + 4 * half);
-            const f32x4 del4 = *(const f32x4*)(del_l + qt * 32 + 8 * g + 4 * half);
+            const f32x4 lse4 = lds_ld128f(lse_l + (qt * 32 + 8 * g) * 4);
+            const f32x4 del4 = lds_ld128f(lse_l + 256 + (qt * 32 + 8 * g) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; e += 2) {   // two elements per instruction
                 const int r = 4 * g + e;
-                float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse4[e]));
-                if (TAIL && (q0 + qt * 32 + reg_row(r, half) >= L)) p = 0.f;
-                if (CAUSAL && (q0 + qt * 32 + reg_row(r, half) < my_key)) p = 0.f;     // a query never attends a later key
-                sacc[r] = p;
-                dp[r] = p * (dp[r] - del4[e]);
+                // p = 2^(s c - lse) as 2^-(lse - s c): the row constant enters the packed fma as it comes out of the LDS (negating it
+                // first cost a v_xor per element), the sign rides on v_exp_f32's source modifier
+                const f32x2 t = __builtin_elementwise_fma((f32x2){sacc[r], sacc[r + 1]}, nc2, (f32x2){lse4[e], lse4[e + 1]});
+                f32x2 p = {__builtin_amdgcn_exp2f(-t[0]), __builtin_amdgcn_exp2f(-t[1])};
+                if (TAIL) {
+                    if (q0 + qt * 32 + reg_row(r, half) >= L) p[0] = 0.f;
+                    if (q0 + qt * 32 + reg_row(r + 1, half) >= L) p[1] = 0.f;
+                }
+                if (CAUSAL) {     // a query never attends a later key
+                    if (q0 + qt * 32 + reg_row(r, half) < my_key) p[0] = 0.f;
+                    if (q0 + qt * 32 + reg_row(r + 1, half) < my_key) p[1] = 0.f;
+                }
+                const f32x2 ds = p * ((f32x2){dp[r], dp[r + 1]} - (f32x2){del4[e], del4[e + 1]});
+                sacc[r] = p[0];
+                sacc[r + 1] = p[1];
+                dp[r] = ds[0];
+                dp[r + 1] = ds[1];
             }
         }
 #pragma unroll
@@ -706,8 +461,8 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD
             const bf16x8 dsf = pack8(dp, sp);
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(do_l, qt * 32, sp, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag<HD>(qt_l, qt * 32, sp, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_a<HD>(do_l, ad, qt * 32, sp, dt), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_a<HD>(qt_l, ad, qt * 32, sp, dt), dsf, dk[dt], 0, 0, 0);
             }
         }
     }
@@ -717,7 +472,7 @@ __device__ __forceinline__ void dkv_tile(const char* qt_l, const bf16x8 (&kf)[HD
 // dK, dV: own rows = keys; streams Q and dO tiles (both row reads and transposed reads) + lse2/delta
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool CAUSAL = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, int L, int H, int nblk, float scale, float scale_log2e,
                                                                int q_begin) {
@@ -755,6 +510,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     constexpr int BUF = 2 * TILE + 512;
     const int nt = (L + 63) / 64;
     const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const TileAddr<HD> ad = tile_addr<HD>(lane, sbase);
+    unsigned lse_a = sbase + 16 * half;
+    asm volatile("" : "+v"(lse_a));
     unsigned qoff[AG<HD>::CH / 4], dooff[AG<HD>::CH / 4];
     stage_offsets<HD>(rs, tid, qoff);
     stage_offsets<HD>(ors, tid, dooff);
@@ -787,20 +545,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         for (int t = t0; t < nt; ++t) {
             const int cur = (t - t0) & 1;
             if (t + 1 < nt) stage(t + 1, cur ^ 1);
-            if (t < nfull && t * 64 >= k0 + 31) dkv_tile<HD, false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
-            else if (t * 64 + 63 >= k0) dkv_tile<HD, true, true>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half, key);
+            if (t < nfull && t * 64 >= k0 + 31) dkv_tile<HD, false>(cur * BUF, lse_a, ad, kf, vf, dk, dv, t * 64, L, scale_log2e, half);
+            else if (t * 64 + 63 >= k0) dkv_tile<HD, true, true>(cur * BUF, lse_a, ad, kf, vf, dk, dv, t * 64, L, scale_log2e, half, key);
             dma_drain();
             __syncthreads();
         }
     } else {
-    for (int t = t0; t < nfull; ++t) {
-        const int cur = (t - t0) & 1;
-        if (t + 1 < nt) stage(t + 1, cur ^ 1);
-        dkv_tile<HD, false>(smem + cur * BUF, kf, vf, dk, dv, t * 64, L, scale_log2e, lane, half);
+    VT_STAMP_DECL;
+    for (int t = t0; t < nfull; t += 2) {     // two tiles per trip: the LDS buffer of a body is an instruction immediate
+        VT_STAMP_START;
+        if (t + 1 < nt) stage(t + 1, 1);
+        dkv_tile<HD, false>(0, lse_a, ad, kf, vf, dk, dv, t * 64, L, scale_log2e, half);
+        VT_STAMP(0);
         dma_drain();
+        VT_STAMP(1);
         __syncthreads();
+        VT_STAMP(2);
+        VT_STAMP_ITER;
+        if (t + 1 < nfull) {
+            if (t + 2 < nt) stage(t + 2, 0);
+            dkv_tile<HD, false>(BUF, lse_a, ad, kf, vf, dk, dv, (t + 1) * 64, L, scale_log2e, half);
+            VT_STAMP(0);
+            dma_drain();
+            VT_STAMP(1);
+            __syncthreads();
+            VT_STAMP(2);
+            VT_STAMP_ITER;
+        }
     }
-    if (nfull < nt) dkv_tile<HD, true>(smem + ((nfull - t0) & 1) * BUF, kf, vf, dk, dv, nfull * 64, L, scale_log2e, lane, half);
+    VT_STAMP_FLUSH(2);
+    if (nfull < nt) dkv_tile<HD, true>(((nfull - t0) & 1) * BUF, lse_a, ad, kf, vf, dk, dv, nfull * 64, L, scale_log2e, half);
     }
     bf16_t* dkb = dqkv + (int64_t)b * L * rs + (int64_t)h * HD + (int64_t)H * HD;
     store_own<DT>(dk, scale, dkb, rs, key, key < L, half);
@@ -822,36 +596,10 @@ __global__ void zero_q_rows_kernel(bf16_t* __restrict__ dqkv, int L, int q_begin
 
 }  // namespace
 
-// Experiment switch for tools/ (environment, read once).  VT_ATTN_PIPE=1 selects the software-pipelined forward below instead of
-// the plain one.  Measured (tools/ab_attn.sh, tools/attn_ablate.sh, profiles/r02_attention_*): the pipelined kernel issues its MFMAs
-// and exponentials perfectly interleaved and runs within +-3 % of the plain kernel on every box (84.6 vs 81.7 us, 86.6 vs 89.5 us),
-// 8 waves per workgroup (half the K/V staging traffic) is 10 % slower, so the plain kernel stays the default.
-static const bool g_attn_plain_fwd = [] { const char* e = getenv("VT_ATTN_PIPE"); return !(e && e[0] == '1'); }();
-static const int g_attn_waves = [] { const char* e = getenv("VT_ATTN_WAVES"); return e ? atoi(e) : 4; }();   // waves per workgroup of the pipelined forward
-static const int g_attn_dbg = [] { const char* e = getenv("VT_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing ablations (wrong results)
-
 template <int HD>
 static void launch_fwd(const void* qkv, int B, int L, int H, int q_begin, void* o, float* lse2, hipStream_t s) {
     const float sl2 = (HD == 64 ? 0.125f : 0.17677669529663688110f) * 1.44269504088896340736f;
     const int nblk = (L - q_begin + 127) / 128;
-    if constexpr (HD == 64) {
-        if (!g_attn_plain_fwd) {
-            const int nw = g_attn_waves == 4 ? 4 : 8;
-            const int nb = (L - q_begin + 32 * nw - 1) / (32 * nw);
-#define VT_LAUNCH_PIPE(D, W) hipLaunchKernelGGL((attn_fwd_pipe_kernel<D, W>), dim3(nb * B * H), dim3(64 * W), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nb, sl2, q_begin)
-#define VT_LAUNCH_PIPE_W(D) if (nw == 4) VT_LAUNCH_PIPE(D, 4); else VT_LAUNCH_PIPE(D, 8)
-            switch (g_attn_dbg) {
-                case 1: VT_LAUNCH_PIPE_W(1); break;
-                case 4: VT_LAUNCH_PIPE_W(4); break;
-                case 16: VT_LAUNCH_PIPE_W(16); break;
-                case 30: VT_LAUNCH_PIPE_W(30); break;
-                default: VT_LAUNCH_PIPE_W(0); break;
-            }
-#undef VT_LAUNCH_PIPE_W
-#undef VT_LAUNCH_PIPE
-            return;
-        }
-    }
     hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3(nblk * B * H), dim3(256), 4 * AG<HD>::TILE, s, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H, nblk, sl2, q_begin);
 }
 
@@ -938,3 +686,9 @@ extern "C" int vt_attention_causal_bwd(const void* qkv, const void* o, const voi
     VT_CHECK_LAUNCH("vt_attention_causal_bwd");
     return VT_OK;
 }
+
+#ifdef VT_ATTN_STAMPS
+extern "C" int vt_attention_stamps(unsigned long long* host_out) {   // diagnostic build only: 3 x 2048 x 4 x 4 counters
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+#endif

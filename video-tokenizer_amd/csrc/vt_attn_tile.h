@@ -78,6 +78,63 @@ __device__ __forceinline__ bf16x8 trfrag(const char* lds, int rbase, int sp, int
     return cat4(lo, hi);
 }
 
+// Round 4: the same two fragments from per-lane byte offsets computed ONCE per kernel.  Everything that depends on the buffer, the tile
+// (K / V / Q / dO image), the 32-row half or the 16-row k-step of a transposed read is a multiple of 16 rows -- the swizzle has period
+// 16 rows -- so it is a compile-time constant the caller adds to the image pointer and hipcc folds into the instruction's offset field.
+// A wave then carries KS + 2 * DT address registers (8 at head_dim 64) and spends no vector instruction on LDS addressing inside
+// the tile loop (ISA audit of the round-3 kernels, profiles/r04_attention_isa_audit.txt: 1.0-1.6 address instructions per MFMA).
+template <int HD>
+struct TileAddr {
+    unsigned k[AG<HD>::KS];        // row fragment of k-step s: row lane & 31
+    unsigned v[AG<HD>::DT][2];     // transposed fragment of column block dt: rows 4 (g >> 1) + (lam >> 2) and + 8
+};
+// `base` = LDS byte address of the first tile image (lds_addr_of(smem)): the registers hold ABSOLUTE LDS addresses, so a read is
+// register + immediate and nothing else (with offsets relative to `smem` hipcc re-added the symbol's address at every use)
+template <int HD>
+__device__ __forceinline__ TileAddr<HD> tile_addr(int lane, unsigned base) {
+    TileAddr<HD> a;
+    const int row = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < AG<HD>::KS; ++s) a.k[s] = base + row * AG<HD>::ROWB + (((2 * s + hf) ^ fsw<HD>(row)) << 4);
+    const int g = lane >> 4, lam = lane & 15;
+    const int r0 = 4 * (g >> 1) + (lam >> 2), r1 = r0 + 8;
+    const int bo = (lam & 1) << 3;
+#pragma unroll
+    for (int dt = 0; dt < AG<HD>::DT; ++dt) {
+        const int lc = ((dt * 32 + 16 * (g & 1)) >> 3) + ((lam & 3) >> 1);
+        a.v[dt][0] = base + r0 * AG<HD>::ROWB + ((lc ^ fsw<HD>(r0)) << 4) + bo;
+        a.v[dt][1] = base + r1 * AG<HD>::ROWB + ((lc ^ fsw<HD>(r1)) << 4) + bo;
+    }
+    // opaque from here on: under register pressure hipcc otherwise re-derives these from the lane id inside the tile loop
+    // (32 v_xor per two tiles in the dK/dV kernel), which is exactly the address arithmetic this struct exists to remove
+#pragma unroll
+    for (int s = 0; s < AG<HD>::KS; ++s) asm volatile("" : "+v"(a.k[s]));
+#pragma unroll
+    for (int dt = 0; dt < AG<HD>::DT; ++dt) {
+        asm volatile("" : "+v"(a.v[dt][0]));
+        asm volatile("" : "+v"(a.v[dt][1]));
+    }
+    return a;
+}
+// img: byte offset of the tile image behind `base` (a compile-time constant in the unrolled loops); r0: first row of the 32-row
+// block (0 or 32).  (r0, s, sp, dt are compile-time constants at every call site once the tile bodies are unrolled.)
+__device__ __forceinline__ bf16x8 lds_ld128(unsigned addr) { return *(const VT_LDS bf16x8*)(uintptr_t)addr; }
+__device__ __forceinline__ f32x4 lds_ld128f(unsigned addr) { return *(const VT_LDS f32x4*)(uintptr_t)addr; }
+__device__ __forceinline__ bf16x4 lds_tr16(unsigned addr) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((VT_LDS s16x4*)(uintptr_t)addr));
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 rowfrag_a(unsigned img, const TileAddr<HD>& a, int r0, int s) {
+    return lds_ld128(a.k[s] + img + r0 * AG<HD>::ROWB);
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 trfrag_a(unsigned img, const TileAddr<HD>& a, int r0, int sp, int dt) {
+    const unsigned cst = img + (r0 + 16 * sp) * AG<HD>::ROWB;
+    return cat4(lds_tr16(a.v[dt][0] + cst), lds_tr16(a.v[dt][1] + cst));
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
 // own 32 rows as B-operand fragments straight from global: f[s] = X[row0 + (lane&31)][16s + 8*(lane>>5) ..+7]
 template <int KS>
 __device__ __forceinline__ void load_own(const bf16_t* __restrict__ src, int64_t rs, int row0, int L, int lane, bf16x8 (&f)[KS]) {

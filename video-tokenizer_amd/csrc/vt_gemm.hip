@@ -538,7 +538,7 @@ constexpr int VT_SPLITK_CTR_BYTES = 4096;   // arrival counters (one per 128x128
 extern "C" size_t vt_gemm_nt_splitk_workspace_bytes(void) { return VT_SPLITK_CTR_BYTES + (size_t)512 * BM * BN * 4; }   // automatic rule: tiles x split <= 2 x 256
 
 int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half);
-int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s);
+int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst);
 int vt_gemm192_init();
 extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
@@ -688,7 +688,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     a.n = n;
     a.tile_start[0] = 0;
     const int g_gemm_variant = ph[0].tile;
-    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 6, "vt_gemm_tn_grouped: tile %d (0 auto, 1 = 128x128, 2 = 192x192)", g_gemm_variant);
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 7, "vt_gemm_tn_grouped: tile %d (0 auto, 1 = 128x128, 2 = 192x192, 7 = 192x192 without the register pipeline)", g_gemm_variant);
     bool big = g_gemm_variant != 1 && (g_gemm_variant < 3 || g_gemm_variant >= 5);  // auto: 192x192 tiles when every problem of the group is at least one tile
     for (int g = 0; g < n; ++g) {
         const vtGemmTN& p = ph[g];
@@ -706,7 +706,7 @@ extern "C" int vt_gemm_tn_grouped(const vtGemmTN* ph, int32_t n, vtStream stream
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        vt_gemm_tn192_launch(ph, n, (hipStream_t)stream);
+        vt_gemm_tn192_launch(ph, n, (hipStream_t)stream, g_gemm_variant == 7);
         VT_CHECK_LAUNCH("vt_gemm_tn_grouped(192)");
         return VT_OK;
     }

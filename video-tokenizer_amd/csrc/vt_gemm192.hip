@@ -629,6 +629,195 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ TN, register-pipelined
+// Round 4: the weight-gradient kernel with the treatment the NT kernel got in round 1.  The kernel above reads a K-tile's 36
+// transposed fragments right behind the barrier that publishes it, so after every barrier all 8 waves burst-read the LDS
+// before the first MFMA can issue (the NT ablation of that pattern: 12 % of the kernel).  Here tile t is multiplied out of one
+// REGISTER set while the 36 reads of tile t+1 go into the other set, three between every row of three MFMAs, and the 6 LDS-DMA
+// pieces of tile t+3 are issued in the middle of the body into the LDS slot tile t vacated one barrier earlier.  All reads are
+// inline asm with explicit waits (one lgkmcnt(0) at the end of a body), DMAs are ordered by a counted vmcnt(6) + raw barrier.
+// Same MFMA order per accumulator as the kernel above (k-half 0 then 1 of every K-tile, tiles ascending): bit-identical output.
+// A fragment's two reads differ by an immediate (rows +4 = +1536 B, swizzle unchanged: f(row) reads row bits 1 and 3), the
+// k-half by another (+32 rows = +12288 B), so a wave carries 9 per-lane base offsets (6 A + 3 B column groups).
+__global__ __launch_bounds__(512, 2) void gemm_tn192p_kernel(const TN192Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = a.tile_start[a.n];
+    const int sid = xcd_remap(blockIdx.x, nwg);
+    int g = 0;
+    while (g + 1 < a.n && sid >= a.tile_start[g + 1]) ++g;
+    const vtGemmTN& p = a.p[g];
+    const int local = sid - a.tile_start[g];
+    const int tiles_q = (p.q_lim + TN_ - 1) / TN_;
+    const int p0 = (local / tiles_q) * TM, q0 = (local % tiles_q) * TN_;
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* B = (const bf16_t*)p.B;
+
+    f32x4 acc[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.M / TK;
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    unsigned aoff[3], boff[3];
+    tn192_piece_offsets(p.lda, p0, p.P, tid, aoff);
+    tn192_piece_offsets(p.ldb, q0, p.Q, tid, boff);
+    auto slot_of = [](int t) { return t % NSTAGE; };
+    auto issue_tile = [&](int t) {
+        const unsigned dst = sbase + slot_of(t) * STAGE_BYTES;
+        stage_tn192(A + (int64_t)t * TK * p.lda, aoff, dst, wave);
+        stage_tn192(B + (int64_t)t * TK * p.ldb, boff, dst + OP_BYTES, wave);
+    };
+    // per-lane byte offset of the first read (rows kb + 8g + q, k-half 0) of column group `col` inside an operand image
+    auto frag_off = [&](int col) {
+        const int gg = lane >> 4, lam = lane & 15;
+        const int q = lam >> 2, pp = lam & 3;
+        const int lc = (col >> 3) + (pp >> 1);
+        const int r0 = 8 * gg + q;
+        const int c0 = (lc & ~7) | ((lc & 7) ^ swz_tn192(r0));
+        return (unsigned)(r0 * 384 + (c0 << 4) + ((pp & 1) << 3));
+    };
+    unsigned fa[6], fb[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fa[i] = frag_off(wm * 96 + i * 16);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fb[j] = OP_BYTES + frag_off(wn * 48 + j * 16);
+
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
+    if (nt > 2) issue_tile(2);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nt > 1) wait_vmcnt6();
+    else wait_vmcnt0();
+    raw_barrier();
+
+    // fragment register sets: lo = rows r0.., hi = rows r0 + 4..; [k-half][column group]
+    bf16x4 xal[2][6], xah[2][6], xbl[2][3], xbh[2][3], yal[2][6], yah[2][6], ybl[2][3], ybh[2][3];
+#define VT_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define VT_TRF(lo, hi, addr, kh)                 \
+    VT_TR(lo, addr, (kh) * 12288);               \
+    VT_TR(hi, addr, (kh) * 12288 + 1536)
+#define VT_MROW(i, kh, Cal, Cah, Cbl, Cbh)                                                                                           \
+    {                                                                                                                                \
+        const bf16x8 af_ = cat4(Cal[kh][i], Cah[kh][i]);                                                                             \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(Cbl[kh][0], Cbh[kh][0]), af_, acc[i][0], 0, 0, 0);                   \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(Cbl[kh][1], Cbh[kh][1]), af_, acc[i][1], 0, 0, 0);                   \
+        acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(Cbl[kh][2], Cbh[kh][2]), af_, acc[i][2], 0, 0, 0);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    }
+    // compute tile from set C while prefetching the tile at LDS address `nb` into set N; DMA of `dma_tile` in the middle
+#define VT_TSTEP(Cal, Cah, Cbl, Cbh, Nal, Nah, Nbl, Nbh, nb)                                                                         \
+    {                                                                                                                                \
+        unsigned na_[6], nb_[3];                                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) na_[i_] = (nb) + fa[i_];                                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) nb_[j_] = (nb) + fb[j_];                                                    \
+        VT_TRF(Nbl[0][0], Nbh[0][0], nb_[0], 0); VT_TR(Nbl[0][1], nb_[1], 0);                                                        \
+        VT_MROW(0, 0, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TR(Nbh[0][1], nb_[1], 1536); VT_TRF(Nbl[0][2], Nbh[0][2], nb_[2], 0);                                                     \
+        VT_MROW(1, 0, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TRF(Nal[0][0], Nah[0][0], na_[0], 0); VT_TR(Nal[0][1], na_[1], 0);                                                        \
+        VT_MROW(2, 0, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TR(Nah[0][1], na_[1], 1536); VT_TRF(Nal[0][2], Nah[0][2], na_[2], 0);                                                     \
+        VT_MROW(3, 0, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TRF(Nal[0][3], Nah[0][3], na_[3], 0); VT_TR(Nal[0][4], na_[4], 0);                                                        \
+        VT_MROW(4, 0, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TR(Nah[0][4], na_[4], 1536); VT_TRF(Nal[0][5], Nah[0][5], na_[5], 0);                                                     \
+        VT_MROW(5, 0, Cal, Cah, Cbl, Cbh);                                                                                           \
+        if (dma_tile >= 0) {                                                                                                         \
+            stage_tn192(A + (int64_t)dma_tile * TK * p.lda, aoff, dma_dst, wave);                                                    \
+            stage_tn192(B + (int64_t)dma_tile * TK * p.ldb, boff, dma_dst + OP_BYTES, wave);                                         \
+        }                                                                                                                            \
+        VT_TRF(Nbl[1][0], Nbh[1][0], nb_[0], 1); VT_TR(Nbl[1][1], nb_[1], 12288);                                                    \
+        VT_MROW(0, 1, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TR(Nbh[1][1], nb_[1], 13824); VT_TRF(Nbl[1][2], Nbh[1][2], nb_[2], 1);                                                    \
+        VT_MROW(1, 1, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TRF(Nal[1][0], Nah[1][0], na_[0], 1); VT_TR(Nal[1][1], na_[1], 12288);                                                    \
+        VT_MROW(2, 1, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TR(Nah[1][1], na_[1], 13824); VT_TRF(Nal[1][2], Nah[1][2], na_[2], 1);                                                    \
+        VT_MROW(3, 1, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TRF(Nal[1][3], Nah[1][3], na_[3], 1); VT_TR(Nal[1][4], na_[4], 12288);                                                    \
+        VT_MROW(4, 1, Cal, Cah, Cbl, Cbh);                                                                                           \
+        VT_TR(Nah[1][4], na_[4], 13824); VT_TRF(Nal[1][5], Nah[1][5], na_[5], 1);                                                    \
+        VT_MROW(5, 1, Cal, Cah, Cbl, Cbh);                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    }
+    {   // fragments of tile 0 (slot 0)
+        unsigned na_[6], nb_[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) na_[i] = sbase + fa[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nb_[j] = sbase + fb[j];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (kh == 0) { VT_TRF(xbl[0][j], xbh[0][j], nb_[j], 0); } else { VT_TRF(xbl[1][j], xbh[1][j], nb_[j], 1); }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (kh == 0) { VT_TRF(xal[0][i], xah[0][i], na_[i], 0); } else { VT_TRF(xal[1][i], xah[1][i], na_[i], 1); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto sync_for = [&](int nx) {   // tile nx landed for every wave; tile nx + 1 may stay in flight
+        if (nx + 1 < nt) wait_vmcnt6(); else wait_vmcnt0();
+        raw_barrier();
+    };
+    for (int t = 0;;) {
+        {
+            const bool more = t + 1 < nt;
+            if (more) sync_for(t + 1);
+            const unsigned nb = sbase + slot_of(more ? t + 1 : t) * STAGE_BYTES;
+            const int dma_tile = t + NSTAGE < nt ? t + NSTAGE : -1;   // into the slot tile t vacated (its fragments are in registers)
+            const unsigned dma_dst = sbase + slot_of(t) * STAGE_BYTES;
+            VT_TSTEP(xal, xah, xbl, xbh, yal, yah, ybl, ybh, nb)
+            if (++t == nt) break;
+        }
+        {
+            const bool more = t + 1 < nt;
+            if (more) sync_for(t + 1);
+            const unsigned nb = sbase + slot_of(more ? t + 1 : t) * STAGE_BYTES;
+            const int dma_tile = t + NSTAGE < nt ? t + NSTAGE : -1;
+            const unsigned dma_dst = sbase + slot_of(t) * STAGE_BYTES;
+            VT_TSTEP(yal, yah, ybl, ybh, xal, xah, xbl, xbh, nb)
+            if (++t == nt) break;
+        }
+    }
+#undef VT_TR
+#undef VT_TRF
+#undef VT_MROW
+#undef VT_TSTEP
+
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pr = p0 + wm * 96 + i * 16 + fr;
+        if (pr >= p.p_lim) continue;
+        const int64_t orow = p.row_perm ? (int64_t)p.row_perm[pr] : (int64_t)pr;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int qc = q0 + wn * 48 + j * 16 + fq * 4;
+            if (qc >= p.q_lim) continue;
+            float* o = p.out + orow * p.ldo + qc;
+            if (qc + 3 < p.q_lim && ((p.ldo & 3) == 0)) {
+                *(f32x4*)o = acc[i][j];
+            } else {
+                for (int r = 0; r < 4 && qc + r < p.q_lim; ++r) o[r] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int g_num_cus = 256;   // set by vt_gemm192_init from the device properties
@@ -663,7 +852,7 @@ int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half) {
     return 0;
 }
 
-int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s) {
+int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst) {
     TN192Args a;
     a.n = n;
     a.tile_start[0] = 0;
@@ -672,7 +861,9 @@ int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s) {
         const int tp = (ph[g].p_lim + TM - 1) / TM, tq = (ph[g].q_lim + TN_ - 1) / TN_;
         a.tile_start[g + 1] = a.tile_start[g] + tp * tq;
     }
-    hipLaunchKernelGGL(gemm_tn192_kernel, dim3(a.tile_start[n]), dim3(512), NSTAGE * STAGE_BYTES, s, a);
+    // burst != 0 (vtGemmTN.tile = 7): the round-1 kernel that reads a tile's fragments behind its barrier, kept for A/B timing
+    if (burst) hipLaunchKernelGGL(gemm_tn192_kernel, dim3(a.tile_start[n]), dim3(512), NSTAGE * STAGE_BYTES, s, a);
+    else hipLaunchKernelGGL(gemm_tn192p_kernel, dim3(a.tile_start[n]), dim3(512), NSTAGE * STAGE_BYTES, s, a);
     return 0;
 }
 
@@ -696,6 +887,7 @@ int vt_gemm192_init() {
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_F32, 2>();
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_DGELU, 2>();
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
     if (e == hipSuccess) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)

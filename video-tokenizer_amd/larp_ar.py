@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from . import hip
 from .embed import get_1d_sincos_pos_embed_from_grid
 from .functional import Linear as LinearFn
+from .pretrained import LocalPretrainedMixin
 from .registry import models as _registry
 
 
@@ -369,7 +370,7 @@ def _pack_swiglu(ff):
     return hit[1]
 
 
-class LARP_AR(nn.Module):
+class LARP_AR(nn.Module, LocalPretrainedMixin):   # from_pretrained / save_pretrained: local directory, PyTorchModelHubMixin's layout (larp_ar.py:233)
     def __init__(self, config: ModelArgs):
         super().__init__()
         self.config = config

@@ -18,6 +18,7 @@ from . import engine as _engine
 from . import hip
 from . import registry
 from .embed import PatchEmbed3D, get_1d_sincos_pos_embed_from_grid, get_3d_sincos_pos_embed
+from .pretrained import LocalPretrainedMixin
 from .registry import register
 
 
@@ -31,7 +32,9 @@ class OutputLayer(nn.Module):
 
 
 @register("larp_tokenizer")
-class LARPTokenizer(nn.Module):
+class LARPTokenizer(nn.Module, LocalPretrainedMixin):
+    # LocalPretrainedMixin: from_pretrained / save_pretrained on a local directory, the layout of the reference's PyTorchModelHubMixin
+    # base (larp_tokenizer.py:45; eval/eval_larp_tokenizer.py:40)
     output_format = "bcthw"
 
     def __init__(self, bottleneck, prior_model=None, bottleneck_token_num=1024, input_size=128, frame_num=16,
@@ -308,6 +311,16 @@ class LARPTokenizer(nn.Module):
     def others_requires_grad_(self, requires_grad):
         for p in self.others_parameters():
             p.requires_grad_(requires_grad)
+
+    def unpatchify(self, x):
+        """larp_tokenizer.py:441-454: (b, n, pt * p * p * c) rows in the reference's (pt, p1, p2, c) column order -> video (b, c, t pt, h p, w p),
+        with the ENCODER-side patch sizes and token_h as the reference uses.  A view + permute of torch (any device); the engine itself
+        never calls it -- its head GEMM runs on row-permuted weights and scatters straight into the video (csrc/vt_patch.hip)."""
+        c, pt, p = self.out_channels, self.temporal_patch_size, self.patch_size
+        h = w = self.token_h
+        t = x.size(1) // (h * w)
+        x = x.reshape(-1, t, h, w, pt, p, p, c)
+        return x.permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(x.shape[0], c, t * pt, h * p, w * p)
 
     @classmethod
     def from_checkpoint(cls, ckpt, load_state_dict=True, version="sd"):

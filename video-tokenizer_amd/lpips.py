@@ -19,6 +19,7 @@ not a kernel of this build and not part of any timed region unless the caller as
 from a state dict the user supplies (`load_lpips_state_dict(path)` reads with `weights_only=True`); without one the module
 keeps a deterministic random init and says so once -- the shipped loss spec then constructs and runs, its perceptual term
 is just not the trained metric."""
+import os
 import warnings
 
 import torch
@@ -105,6 +106,7 @@ class LPIPS(nn.Module):
             setattr(self, f"lin{n}", h)
         self.lins = nn.ModuleList(heads)
         self.weights_loaded = False
+        self._warned_random = False      # per instance (a class-level flag hid the second model of a process)
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():
             for p in self.parameters():
@@ -134,10 +136,17 @@ class LPIPS(nn.Module):
 
     def forward(self, in0, in1, normalize=False):
         """normalize=True: inputs in [0, 1] are mapped to [-1, 1] first (how the reference calls it, models/loss.py:335, 370-372)"""
-        if not self.weights_loaded and not getattr(LPIPS, "_warned", False):
-            LPIPS._warned = True
-            warnings.warn("LPIPS runs on its random init: no VGG / lin weights were supplied (load_lpips_state_dict or a checkpoint "
-                          "that carries perceptual_loss.*); the perceptual term is not the trained metric", stacklevel=2)
+        if not self.weights_loaded:
+            # The reference always runs the TRAINED metric (lpips.LPIPS downloads its weights, models/loss.py:241).  Optimising or
+            # reporting against a random-init VGG is a different objective, so it is an error unless asked for explicitly
+            # (VT_LPIPS_ALLOW_RANDOM=1: the tests and the bench, which only need the arithmetic and the time).
+            if os.environ.get("VT_LPIPS_ALLOW_RANDOM") != "1":
+                raise RuntimeError("LPIPS has no trained weights: supply them (VT_LPIPS_WEIGHTS=<state dict of lpips.LPIPS(net='vgg')>, "
+                                   "load_lpips_state_dict(), or a checkpoint whose `loss` entry carries perceptual_loss.*), set "
+                                   "perceptual_weight to 0, or opt in to the random-init network with VT_LPIPS_ALLOW_RANDOM=1")
+            if not self._warned_random:
+                self._warned_random = True
+                warnings.warn("LPIPS runs on its random init (VT_LPIPS_ALLOW_RANDOM=1): the perceptual term is not the trained metric", stacklevel=2)
         dt = self.scaling_layer.shift.dtype
         if normalize:
             in0, in1 = 2 * in0 - 1, 2 * in1 - 1
