@@ -203,21 +203,6 @@ int vt_attention_fwd_rows(const void* qkv, int32_t B, int32_t L, int32_t H, int3
                           vtStream stream);
 int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
                           int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, vtStream stream);
-/* The same backward (head_dim 64, no mask; q_begin as above) in FIVE matrix products instead of seven: one kernel, one
- * workgroup per 256 keys of a (batch, head) keeps dK / dV in registers and computes S, dP and the softmax once; dQ is summed
- * across the key blocks of a head by an ordered hand-off through `ws` (fixed summation order: results are bit-reproducible
- * run to run; no atomics on data).  `ws` (vt_attention_bwd_fused_workspace_bytes, 16-byte aligned) holds the fp32 partial
- * sums, the arrival counters and a status word; the call zeroes its control block itself (graph-capturable, nothing
- * allocates or synchronises); the caller zeroes the whole workspace ONCE before its first use.  Every in-kernel wait is
- * bounded: if one gives up, the kernel still terminates and sets the STICKY status word (the last 16 bytes of `ws`;
- * vt_attention_bwd_fused_status reads it and synchronises the stream): != 0 means the outputs of some launch on this
- * workspace are invalid.
- * Replaces autograd of F.scaled_dot_product_attention under models/transformer.py:52-59. */
-size_t vt_attention_bwd_fused_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t hd, int32_t q_begin);
-int vt_attention_bwd_fused(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
-                           int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, void* ws, size_t ws_bytes,
-                           vtStream stream);
-int vt_attention_bwd_fused_status(const void* ws, size_t ws_bytes, int32_t* status, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Vector quantisation (SimpleVectorQuantizer.forward, models/bottleneck.py:262-324).
@@ -446,8 +431,6 @@ int vt_tokenizer_codes_to_encoded(vtTokenizer* tk, const vtTokenizerTensors* par
  * may become final a few stages later: *final_through (optional) receives the number of leading stages
  * whose gradients are complete once the enqueued work has run. */
 int32_t vt_tokenizer_num_backward_stages(const vtTokenizer* tk);
-/* byte offset inside the workspace of the attention backward's sticky status word (see vt_attention_bwd_fused), 0 if unused */
-size_t vt_tokenizer_status_offset(const vtTokenizer* tk);
 /* device-side per-call counter of the stochastic quantizer (see vt_vq_forward_ctr); NULL (the default) = the by-value seed alone */
 int vt_tokenizer_set_seed_counter(vtTokenizer* tk, const uint32_t* seed_counter);
 /* Split K in the BACKWARD input-gradient GEMMs that would leave most CUs idle (vtGemmNT.splitk_ws; one or two clips per GPU): on by

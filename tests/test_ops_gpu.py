@@ -475,58 +475,6 @@ def _attn_grad_ref_cuda(qkv, dO, B, L, H, q_begin):
     return x.grad
 
 
-@pytest.mark.parametrize("B,L,H,q_begin", [(1, 64, 1, 0), (2, 192, 3, 0), (1, 100, 2, 0), (1, 333, 1, 0), (1, 256, 1, 0), (2, 512, 2, 0),
-                                            (1, 1040, 2, 0), (3, 700, 2, 0), (2, 192, 2, 64), (1, 320, 3, 128), (1, 1536, 2, 1024),
-                                            (2, 1536, 1, 512), (1, 2048, 3, 0)])
-def test_attention_bwd_fused_five_products(hip, B, L, H, q_begin):
-    """vt_attention_bwd_fused (one kernel, dQ summed across the 256-key blocks by the ordered hand-off) against fp32 math and
-    against the two-kernel backward, for single and multi-block chains, ragged keys / queries and kept-query suffixes; the
-    status word must stay 0 (no bounded spin gave up) and a second launch must reproduce every bit."""
-    qkv = bf(_rand((B * L, 3 * H * 64), 250 + L + q_begin))
-    Lq = L - q_begin
-    dO = bf(_rand((B * Lq, H * 64), 251 + L))
-    g = _attn_grad_ref_cuda(qkv, dO, B, L, H, q_begin)
-    o, lse2 = hip.attention_fwd(qkv.cuda(), B, L, H, 64, q_begin=q_begin)
-    d_split = hip.attention_bwd(qkv.cuda(), o, dO.cuda(), lse2, B, L, H, 64, q_begin=q_begin, fused=False)
-    d_fused = torch.full_like(d_split, float("nan"))
-    hip.attention_bwd(qkv.cuda(), o, dO.cuda(), lse2, B, L, H, 64, dqkv=d_fused, q_begin=q_begin, fused=True)
-    assert hip.attention_bwd_fused_status(hip.attention_bwd.last_ws) == 0
-    assert torch.isfinite(d_fused.float()).all()
-    scale = g.abs().max()
-    assert (d_fused.float() - g).abs().max() / scale < 3e-2
-    assert (d_fused.float() - d_split.float()).abs().max() / scale < 1e-2       # same operands, same rounding points: summation order only
-    if q_begin:
-        assert torch.all(d_fused.reshape(B, L, 3, H * 64)[:, :q_begin, 0] == 0)
-    again = torch.full_like(d_split, float("nan"))
-    hip.attention_bwd(qkv.cuda(), o, dO.cuda(), lse2, B, L, H, 64, dqkv=again, q_begin=q_begin, fused=True)
-    torch.cuda.synchronize()
-    assert torch.equal(again, d_fused)
-
-
-def test_attention_bwd_fused_headline_shape_under_load(hip):
-    """The step's shape (8 clips, 12 heads, L = 1536: 576 work items of 6-block chains on 256 CUs, i.e. 2.25 rounds of the work
-    queue, chains whose members start at different times): 12 back-to-back launches into ONE workspace must all give the bits
-    of the first, status 0, and match fp32 math; then the same with every second launch preceded by a memory-bound kernel, so
-    chain members start on a busy chip (uneven load)."""
-    B, L, H = 8, 1536, 12
-    qkv = bf(_rand((B * L, 3 * H * 64), 401)).cuda()
-    dO = bf(_rand((B * L, H * 64), 402)).cuda()
-    o, lse2 = hip.attention_fwd(qkv, B, L, H, 64)
-    first = hip.attention_bwd(qkv, o, dO, lse2, B, L, H, 64, fused=True).clone()
-    ws = hip.attention_bwd.last_ws
-    assert hip.attention_bwd_fused_status(ws) == 0
-    g = _attn_grad_ref_cuda(qkv.cpu(), dO.cpu(), B, L, H, 0)
-    assert (first.float() - g).abs().max() / g.abs().max() < 3e-2
-    del g
-    junk = torch.empty(64 << 20, device="cuda")
-    for it in range(12):
-        if it & 1:
-            junk.mul_(1.0001)
-        out = hip.attention_bwd(qkv, o, dO, lse2, B, L, H, 64, fused=True)
-        assert hip.attention_bwd_fused_status(hip.attention_bwd.last_ws) == 0, it
-        assert torch.equal(out, first), it
-
-
 @pytest.mark.parametrize("hd", [64, 32])
 def test_attention_integer_identity(hip, hd):
     """One-hot V columns + peaked scores: checks the transposed-read PV product element by element."""

@@ -27,7 +27,10 @@ def _worker(rank, world, port, q):
         torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's weights
         m = vt.make(spec_from_cfg(O.make_cfg("tiny"), stochastic=True))
         dp = DataParallelTokenizer(m, bucket_bytes=4 << 20)
-        chk = torch.cat([p.detach().reshape(-1)[:4] for p in m.parameters()])
+        # every element of every parameter and buffer (the trainable ones travel as ONE flat-buffer broadcast since round 4)
+        chk = torch.cat([p.detach().double().reshape(-1)[:64] for p in list(m.parameters()) + list(m.buffers())] +
+                        [torch.stack([p.detach().double().sum() for p in list(m.parameters()) + list(m.buffers())])])
+        assert m._engine.flat_param is not None and all(p.data_ptr() >= m._engine.flat_param.data_ptr() for p in m.parameters() if p.requires_grad)
         gathered = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(gathered, chk)
         same = all(torch.equal(gathered[0], g) for g in gathered)

@@ -18,12 +18,12 @@ for _ in range(20):     # clocks settle
     o, lse = hip.attention_fwd(qkv, B, L, H)
     d = hip.attention_bwd(qkv, o, dO, lse, B, L, H)
 torch.cuda.synchronize()
-buf = (ctypes.c_uint64 * (3 * 2048 * 4 * 4))()
+buf = (ctypes.c_uint64 * (3 * 2048 * 4 * 6))()
 fn = hip.lib().vt_attention_stamps
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
-t = torch.tensor(list(buf), dtype=torch.float64).reshape(3, 2048, 4, 4)
+t = torch.tensor(list(buf), dtype=torch.float64).reshape(3, 2048, 4, 6)
 nwg = B * H * ((L + 127) // 128)
 for k, name in enumerate(("fwd", "dq", "dkv")):
     x = t[k, :nwg]                                   # [wg, wave, 4]
@@ -38,3 +38,15 @@ for k, name in enumerate(("fwd", "dq", "dkv")):
             print(f"     {label:30s} body {y[..., 0].mean():.0f}  dma-wait {y[..., 1].mean():.0f}  barrier {y[..., 2].mean():.0f}")
     w = per.mean(0)                                  # per wave index
     print("     by wave: " + "  ".join(f"w{i}: {w[i, 0]:.0f}/{w[i, 1]:.0f}/{w[i, 2]:.0f}" for i in range(4)))
+    # timeline (s_memrealtime, 100 MHz): when do workgroups start / end relative to the first start, and the shader clock they ran at
+    t0 = x[..., 4].min()
+    start, end = (x[:, 0, 4] - t0) / 100.0, (x[:, 0, 5] - t0) / 100.0          # us, wave 0 of each workgroup
+    cyc = x[:, 0, :3].sum(-1)
+    clk = cyc / ((end - start) * 1e3)                                          # cycles per ns = GHz
+    order = torch.argsort(start)
+    q = lambda v, f: v.kthvalue(max(1, int(f * v.numel())))[0].item()
+    print(f"     loop start (us after the first): 50% {q(start, .5):.1f}  89% {q(start, .89):.1f}  95% {q(start, .95):.1f}  last {start.max().item():.1f};  "
+          f"loop end: first {end.min().item():.1f}  50% {q(end, .5):.1f}  last {end.max().item():.1f};  loop duration: 10% {q(end - start, .1):.1f}  50% {q(end - start, .5):.1f}  90% {q(end - start, .9):.1f} us;  "
+          f"shader clock in the loop: 10% {q(clk, .1):.2f}  50% {q(clk, .5):.2f}  90% {q(clk, .9):.2f} GHz")
+    late = start > 0.5 * end.max()
+    print(f"     workgroups that start in the second half of the kernel: {int(late.sum())} (loop duration {((end - start)[late]).mean().item() if late.any() else 0:.1f} us vs {((end - start)[~late]).mean().item():.1f} us for the others)")

@@ -19,5 +19,5 @@ for b in 1 2 4; do
     python3 bench.py --batch $b --steps 30 --warmup 5 --optimizer fused --no-cpu-baseline --no-roofline $g > $O/bench_b${b}${g}.json 2> $O/bench_b${b}${g}.err || echo "bench b$b $g failed"
   done
 done
-python3 tools/attn_bwd_ab.py 5 10 > $O/attn_bwd_ab.log 2>&1 || echo "attention A/B failed"
+# (round 4: tools/attn_bwd_ab.py left the tree with vt_attention_bwd_fused; its records are profiles/r03_attention_bwd_*)
 ls -la $O

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["vt_api.cpp", "vt_gemm.hip", "vt_gemm192.hip", "vt_norm.hip", "vt_patch.hip", "vt_vq.hip", "vt_attention.hip", "vt_attention_bwd.hip", "vt_optim.hip", "vt_fsq.hip", "vt_gated.hip", "vt_ar.hip", "vt_engine.hip", "vt_gated_engine.hip"]
-AUDIT_NO_SPILL = {"vt_gemm192.hip", "vt_attention.hip", "vt_attention_bwd.hip"}
+SOURCES = ["vt_api.cpp", "vt_gemm.hip", "vt_gemm192.hip", "vt_norm.hip", "vt_patch.hip", "vt_vq.hip", "vt_attention.hip", "vt_optim.hip", "vt_fsq.hip", "vt_gated.hip", "vt_ar.hip", "vt_engine.hip", "vt_gated_engine.hip"]
+AUDIT_NO_SPILL = {"vt_gemm.hip", "vt_gemm192.hip", "vt_attention.hip"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

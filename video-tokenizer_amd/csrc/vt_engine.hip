@@ -17,9 +17,7 @@
 
 #include "vt_common.h"
 
-// VT_ATTN_BWD=fused (read once): see attn_bwd() below
 static const bool g_no_splitk = [] { const char* e = getenv("VT_GEMM_SPLITK"); return e && strcmp(e, "0") == 0; }();   // A/B switch, read once
-static const bool g_attn_bwd_fused = [] { const char* e = getenv("VT_ATTN_BWD"); return e && strcmp(e, "fused") == 0; }();
 
 namespace {
 
@@ -92,7 +90,6 @@ struct vtTokenizer {
     bool splitk_on = !g_no_splitk;           // vt_tokenizer_set_split_k / vt_stack_set_split_k; VT_GEMM_SPLITK=0 starts it off
     bool in_backward = false;                // set by the entry points: nt() hands the split-K workspace to backward GEMMs only
     size_t splitk = 0, splitk_bytes = 0;     // vt_gemm_nt's split-K partial sums + arrival counters (zeroed by *_init_workspace)
-    size_t attn_ws = 0, attn_ws_bytes = 0;   // five-product attention backward: partial dQ sums + hand-off counters (head_dim 64)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
     // deferred into one grouped launch, so these rotate over WG_BATCH + 1 sets (the set a block writes its dx_in to
     // is the next block's dx_out set).
@@ -203,8 +200,6 @@ extern "C" int vt_tokenizer_create(const vtTokenizerConfig* cfg, vtTokenizer** o
         lb.dxa = a.take((size_t)lb.Mkp * D * 2); lb.dxm = a.take((size_t)lb.Mkp * D * 2); lb.du = a.take((size_t)lb.Mkp * t->D4 * 2);
     }
     t->delta = a.take((size_t)c.B * c.H * t->L * 4);
-    t->attn_ws_bytes = g_attn_bwd_fused ? vt_attention_bwd_fused_workspace_bytes(c.B, t->L, c.H, c.D / c.H, 0) : 0;   // q_begin = 0: the largest plan
-    t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
     t->splitk_bytes = vt_gemm_nt_splitk_workspace_bytes();
     t->splitk = a.take(t->splitk_bytes);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(c.D));
@@ -234,12 +229,6 @@ extern "C" int vt_tokenizer_set_seed_counter(vtTokenizer* t, const uint32_t* see
     t->seed_ctr = seed_counter;
     return VT_OK;
 }
-// byte offset inside the workspace of the attention backward's sticky status word (vt_attention_bwd_fused), 0 if that kernel is not in use
-extern "C" size_t vt_tokenizer_status_offset(const vtTokenizer* t) {
-    if (!t || !t->attn_ws_bytes) return 0;
-    return t->attn_ws + (t->attn_ws_bytes / 16) * 16 - 16;
-}
-
 extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream stream) {
     VT_CHECK_ARG(t && ws, "vt_tokenizer_init_workspace: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -251,15 +240,11 @@ extern "C" int vt_tokenizer_init_workspace(vtTokenizer* t, void* ws, vtStream st
     return VT_OK;
 }
 
-// Attention backward of one block.  Default: the two-kernel form (dQ kernel + dK/dV kernel, 7 products).  VT_ATTN_BWD=fused (read
-// once) selects the five-product kernel with the ordered dQ hand-off for the blocks where its chains have slack (head_dim 64,
-// at least 3 query slices per key block): correct and bit-reproducible, but measured SLOWER on this chip as hipcc builds it
-// (346 vs 244 us at the step's shape, profiles/r03_attention_bwd_*): kept selectable as the record of the experiment and for A/B.
+// Attention backward of one block: the two-kernel form (dQ kernel + dK/dV kernel, 7 products).  The five-product kernel with an ordered
+// dQ hand-off that round 3 built was correct and bit-reproducible but slower (346 vs 244 us at the step's shape) and left the tree in
+// round 4; its record: DESIGN.md section 5 "Attention backward, round 3", profiles/r03_attention_bwd_*.
 static int attn_bwd(vtTokenizer* t, void* ws, const void* qkv, const void* o, const void* dO, const float* lse, int q_begin, void* dqkv, vtStream s) {
     const vtTokenizerConfig& c = t->c;
-    const int nsl = (t->L - q_begin + 63) / 64, nkb = (t->L + 255) / 256;
-    if (g_attn_bwd_fused && t->attn_ws_bytes && nsl >= 3 * nkb)
-        return vt_attention_bwd_fused(qkv, o, dO, lse, c.B, t->L, c.H, c.D / c.H, q_begin, dqkv, WS(float, t->delta), WS(void, t->attn_ws), t->attn_ws_bytes, s);
     return vt_attention_bwd_rows(qkv, o, dO, lse, c.B, t->L, c.H, c.D / c.H, q_begin, dqkv, WS(float, t->delta), s);
 }
 
@@ -757,8 +742,6 @@ extern "C" int vt_stack_create(const vtStackConfig* cfg, vtStack** out) {
     }
     t->dh = a.take(Mp * D * 2); t->dob = a.take(Mp * D * 2);
     t->delta = a.take((size_t)B * H * L * 4);
-    t->attn_ws_bytes = g_attn_bwd_fused ? vt_attention_bwd_fused_workspace_bytes(B, L, H, D / H, 0) : 0;   // 0: two-kernel backward
-    t->attn_ws = a.take(t->attn_ws_bytes ? t->attn_ws_bytes : 16);
     t->splitk_bytes = vt_gemm_nt_splitk_workspace_bytes();
     t->splitk = a.take(t->splitk_bytes);
     t->ln_ws = a.take(vt_layernorm_bwd_workspace_bytes(D));

@@ -145,12 +145,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
             int ra = m0 + row, rb = n0 + row;
             ra = ra < p.M ? ra : p.M - 1;
             rb = rb < p.N ? rb : p.N - 1;
-            offa[i] = (unsigned)(((int64_t)ra * p.lda + lc * 8) * 2);
-            offb[i] = (unsigned)(((int64_t)rb * p.ldb + lc * 8) * 2);
+            // relative to the tile's first row (<= 127 rows x ld): the 32-bit lane offset cannot wrap however large M x lda is
+            // (absolute rows wrapped beyond 4 GiB of operand; the tile's base moves into the scalar pointer instead)
+            offa[i] = (unsigned)(((int64_t)(ra - m0) * p.lda + lc * 8) * 2);
+            offb[i] = (unsigned)(((int64_t)(rb - n0) * p.ldb + lc * 8) * 2);
         }
+        const bf16_t* Atile = A + (int64_t)m0 * p.lda;
+        const bf16_t* Btile = B + (int64_t)n0 * p.ldb;
         auto issue = [&](int t, int slot) {
-            const bf16_t* ak = A + (int64_t)t * BK;
-            const bf16_t* bk = B + (int64_t)t * BK;
+            const bf16_t* ak = Atile + (int64_t)t * BK;
+            const bf16_t* bk = Btile + (int64_t)t * BK;
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16_sv(ak, offa[i], sbase + slot * STAGE + (i * 256 + wave * 64) * 16);
 #pragma unroll

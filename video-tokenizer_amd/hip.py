@@ -68,9 +68,6 @@ SIGNATURES = {
     "vt_attention_causal_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_fwd_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "vt_attention_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
-    "vt_attention_bwd_fused_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "vt_attention_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "vt_attention_bwd_fused_status": (c_i32, [c_vp, c_sz, ctypes.POINTER(c_i32), c_vp]),
     "vt_vq_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vt_vq_forward": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_u64, c_vp, c_vp,
                               c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -174,7 +171,6 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_decode": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_codes_to_encoded": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, c_vp]),
     "vt_tokenizer_num_backward_stages": (c_i32, [c_vp]),
-    "vt_tokenizer_status_offset": (c_sz, [c_vp]),
     "vt_tokenizer_set_seed_counter": (c_i32, [c_vp, c_vp]),
     "vt_tokenizer_set_split_k": (c_i32, [c_vp, c_i32]),
     "vt_stack_set_split_k": (c_i32, [c_vp, c_i32]),
@@ -399,29 +395,12 @@ def attention_fwd(qkv, B, L, H, hd=64, o=None, q_begin=0):
     return o, lse2
 
 
-def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0, fused=None):
-    """fused=True: the five-product kernel with the ordered dQ hand-off (head_dim 64); default: the two-kernel backward, which is
-    the faster one as measured (DESIGN.md §5 "Attention backward, round 3")"""
+def attention_bwd(qkv, o, dO, lse2, B, L, H, hd=64, dqkv=None, q_begin=0):
+    """the two-kernel backward (dQ + dK/dV, recompute from lse2); dqkv in the packed layout of qkv"""
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     delta = torch.zeros(B, H, L, device=qkv.device, dtype=torch.float32)
-    if fused:
-        n = lib().vt_attention_bwd_fused_workspace_bytes(B, L, H, hd, q_begin)
-        if n == 0:
-            raise HipError(f"vt_attention_bwd_fused: unsupported geometry B={B} L={L} H={H} hd={hd} q_begin={q_begin}")
-        ws = torch.zeros(n, dtype=torch.uint8, device=qkv.device)     # zeroed once: the status word is sticky
-        check(lib().vt_attention_bwd_fused(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), ptr(ws), n, stream()),
-              "vt_attention_bwd_fused")
-        attention_bwd.last_ws = ws
-        return dqkv
     check(lib().vt_attention_bwd_rows(ptr(qkv), ptr(o), ptr(dO), ptr(lse2), B, L, H, hd, q_begin, ptr(dqkv), ptr(delta), stream()), "vt_attention_bwd")
     return dqkv
-
-
-def attention_bwd_fused_status(ws):
-    """sticky status word of a fused-backward workspace (`attention_bwd.last_ws`; synchronises the stream): 0 = every hand-off completed"""
-    st = c_i32(0)
-    check(lib().vt_attention_bwd_fused_status(ptr(ws), ws.numel(), ctypes.byref(st), stream()), "vt_attention_bwd_fused_status")
-    return st.value
 
 
 def attention_causal_fwd(qkv, B, L, H):

@@ -159,7 +159,8 @@ def _discriminator_torch_ops(D, x):
     H, hd = D.n_head, D.hidden_size // D.n_head
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         emb = D.x_embedder
-        w = emb.proj.weight if emb.proj.weight.dim() == 5 else emb.proj.weight.unsqueeze(2)      # VideoPatchEmbed: a Conv2d per frame
+        w = emb.proj.weight      # read ONCE: under the spectral-norm parametrization every read of `.weight` in train mode is a power iteration
+        w = w if w.dim() == 5 else w.unsqueeze(2)      # VideoPatchEmbed: a Conv2d per frame
         tok = F.conv3d(x, w, emb.proj.bias, stride=w.shape[2:]).flatten(2).transpose(1, 2).float() + D.encoder_pos_embed
         h = torch.cat((D.cls_token.float().expand(b, -1, -1), tok), dim=1)
         for blk in D.transformer_encoder.blocks:
@@ -299,6 +300,11 @@ class VQLPIPSWithDiscriminator(nn.Module):
             r1_gp = zero
             if self.training and self.r1_gp_weight > 0.0:      # loss.py:415-418: the real logits come out of the penalty's own forward
                 logits_real, r1_gp = _r1_gradient_penalty(self.discriminator, inputs.contiguous(), self.r1_gp_weight)
+                logits_fake = self.discriminator(reconstructions.detach().contiguous())
+            elif self.spectral_norm:
+                # the parametrization advances its power iteration once per training forward: the reference's two calls (:417-424) take
+                # two steps per update and the fake logits see the second sigma, so the two calls are kept apart here as well
+                logits_real = self.discriminator(inputs.contiguous())
                 logits_fake = self.discriminator(reconstructions.detach().contiguous())
             else:
                 logits = self.discriminator(torch.cat([inputs, reconstructions.detach()], dim=0))

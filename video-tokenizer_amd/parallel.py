@@ -95,14 +95,23 @@ class DataParallelTokenizer(nn.Module):
         super().__init__()
         self.module = module
         self.process_group = process_group
-        if dist.get_world_size(process_group) > 1:
-            with torch.no_grad():
-                for t in list(module.parameters()) + list(module.buffers()):
-                    dist.broadcast(t, src=0, group=process_group)
         if getattr(module, "_engine", None) is None:
             why = getattr(module, "_composed_why", None)
             raise NotImplementedError("this model runs on the composed path (no fused engine" + (f": {why}" if why else "") + "): its gradients are "
                                       "ordinary .grad tensors, wrap it in torch.nn.parallel.DistributedDataParallel")
+        if dist.get_world_size(process_group) > 1:
+            # rank 0's weights to everyone (DDP's constructor does the same): the trainable parameters sit in ONE flat buffer
+            # (optim.flatten_parameters, idempotent), so they travel as one collective instead of 277; frozen parameters and the three
+            # position-embedding buffers follow one by one
+            from .optim import flatten_parameters
+            with torch.no_grad():
+                flat = flatten_parameters(module)
+                dist.broadcast(flat, src=0, group=process_group)
+                inside = {p.data_ptr() for p in module.parameters()
+                          if flat.data_ptr() <= p.data_ptr() < flat.data_ptr() + flat.numel() * flat.element_size()}
+                for t in list(module.parameters()) + list(module.buffers()):
+                    if t.data_ptr() not in inside:
+                        dist.broadcast(t, src=0, group=process_group)
         module._engine.reducer = GradReducer(process_group, bucket_bytes)
 
     def forward(self, *a, **k):
