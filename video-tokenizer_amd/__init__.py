@@ -4,6 +4,14 @@ Host-side mirror of the reference's model-registry interface over the C ABI of l
 (include/vt_hip.h).  There is no CPU fallback: every compute entry point raises if the HIP
 library is missing or the tensors are not on a GPU.
 """
+import os as _os
+
+# Graph replays (engine.GraphedStep, the AR prior's decode loop) are only correct on this ROCm build with the runtime's graph PACKET
+# CAPTURE off: with it, a kernel node of a replay can read a small tensor an earlier node of the same replay wrote as the PREVIOUS
+# replay left it (round 4: tools/graph_stale_scalar_check.sh, profiles/r04_graph_stale_scalar.log, DESIGN 6b).  The runtime reads the
+# flag once, when the process first touches HIP; an explicit setting of the user is respected.
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 from . import hip  # noqa: F401  (ctypes binding; loading is lazy)
 from . import config  # noqa: F401
 from .registry import make, models, register  # noqa: F401

@@ -32,12 +32,6 @@
 // Diagnostic build only (-DVT_ATTN_STAMPS, tools/attn_stamps.sh): s_memtime stamps around the three segments of a tile iteration
 // (tile body = staging issue + MFMA / softmax | s_waitcnt vmcnt(0) on the next tile's LDS-DMA | workgroup barrier), summed per wave.
 // The shares are what to read, never the run time (cdna_hip_programming.md section 7, "In-kernel stamps").
-// -DVT_ATTN_PRIO (A/B builds only, tools/ab_variant.sh): raise the wave's issue priority around its MFMA clusters (guide T5)
-#ifdef VT_ATTN_PRIO
-#define VT_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define VT_PRIO(x)
-#endif
 #ifdef VT_ATTN_STAMPS
 __device__ unsigned long long g_attn_stamps[3][2048][4][6];     // [kernel: fwd, dq, dkv][workgroup][wave][body, drain, barrier, iterations, realtime at loop start, at loop end (100 MHz)]
 #define VT_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, __builtin_amdgcn_s_memrealtime(), 0}
@@ -71,7 +65,6 @@ template <int HD, bool TAIL>
 __device__ __forceinline__ void fwd_tile(unsigned kl, unsigned vl, const TileAddr<HD>& ad, const bf16x8 (&qf)[HD / 16], f32x16 (&oacc)[HD / 32],
                                          float& m, float& lsum, int key0, int L, float c, int half) {
     f32x16 sacc[2];
-    VT_PRIO(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -80,7 +73,6 @@ __device__ __forceinline__ void fwd_tile(unsigned kl, unsigned vl, const TileAdd
         for (int s = 0; s < HD / 16; ++s)
             sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag_a<HD>(kl, ad, kt * 32, s), qf[s], sacc[kt], 0, 0, 0);
     }
-    VT_PRIO(0);
     float mx = -__builtin_inff();
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -119,7 +111,6 @@ __device__ __forceinline__ void fwd_tile(unsigned kl, unsigned vl, const TileAdd
             sacc[kt][r + 1] = pv[1];
         }
     lsum += ps2[0] + ps2[1];
-    VT_PRIO(1);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -129,7 +120,6 @@ __device__ __forceinline__ void fwd_tile(unsigned kl, unsigned vl, const TileAdd
             for (int dt = 0; dt < HD / 32; ++dt)
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_a<HD>(vl, ad, kt * 32, sp, dt), pf, oacc[dt], 0, 0, 0);
         }
-    VT_PRIO(0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,8 +12,17 @@
 // v_mfma_f32_16x16x32_bf16; the two waves of a SIMD interleave LDS reads with MFMAs.
 //   NT: fragments by ds_read_b128 from [192][64] images (128-B rows, chunk ^= (row>>1)&7).
 //   TN: fragments by ds_read_b64_tr_b16 from [64][192] images (384-B rows, low 3 chunk bits ^= f(row)).
+#include <stdlib.h>
+
 #include "vt_common.h"
 #include "vt_gemm_epilogue.h"
+
+// -DVT_GEMM_STORE8 (A/B builds only, tools/ab_variant.sh): keep the 8-byte epilogue stores of rounds 1-3
+#ifdef VT_GEMM_STORE8
+constexpr bool kStore16 = false;
+#else
+constexpr bool kStore16 = true;
+#endif
 
 namespace {
 
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             // the epilogue's per-thread coordinates are recomputed per output tile: hoisted out of the persistent loop they would
             // sit in registers across the main loop, which has none to spare (256 allocated, spill-free)
             int tid_e = tid;
-            if constexpr (TABLE) asm volatile("" : "+v"(tid_e));
+            if constexpr (EPI != VT_EPI_BF16_DGELU) asm volatile("" : "+v"(tid_e));   // (the gelu' instantiation sits at 256 registers and spills WITH it)
             const int fr_e = tid_e & 15, fq_e = (tid_e & 63) >> 4;
             // bf16 outputs leave through LDS: after the swapped MFMA a lane owns 4 consecutive columns of 16 different
             // rows, so a direct store instruction touches 16 cache lines with 32 B each (the K -> 0 intercept of
@@ -378,6 +387,54 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 #pragma unroll
                         for (int r = 0; r < RL; ++r) sum += red[r * G::TNW + tid_e];
                         p.colsum_partial[(int64_t)(em0 / TM) * p.N + en0 + tid_e] = sum;
+                    }
+                }
+                continue;
+            }
+            // Round 4: 16 bytes per lane on the way out (two 8-byte image reads, ONE global_store_dwordx4: a wave instruction writes 1 KiB).
+            // 8-byte accesses run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH, visibility table) and the epilogue is what a round
+            // of this kernel pays outside its main loop (6-13 us, all 256 CUs storing at once).  Needs 8-column alignment of the output.
+            if (kStore16 && a.dbg == 0 && (p.N & 7) == 0 && (p.ldo & 7) == 0 && (EPI != VT_EPI_BF16_GELU || (p.ldo2 & 7) == 0)) {
+                constexpr int UPR16 = G::TNW / 8;                        // 16-B units per tile row
+                constexpr int NIT16 = TM * UPR16 / G::THREADS, RB16 = 3;
+                static_assert(NIT16 % RB16 == 0, "read-back batches");
+#pragma unroll 1
+                for (int it0 = 0; it0 < NIT16; it0 += RB16) {
+                    bf16x8 hh[RB16];
+#pragma unroll
+                    for (int u = 0; u < RB16; ++u) {
+                        const int slot = (it0 + u) * G::THREADS + tid_e;
+                        const int row = slot / UPR16, c = slot - row * UPR16;
+                        const char* src = smem + row * STRIDE + c * 16;     // 8-byte aligned (row stride 392)
+                        hh[u] = cat4(*(const bf16x4*)src, *(const bf16x4*)(src + 8));
+                    }
+#pragma unroll
+                    for (int u = 0; u < RB16; ++u) {
+                        const int slot = (it0 + u) * G::THREADS + tid_e;
+                        const int row = slot / UPR16, c = slot - row * UPR16;
+                        const int m = em0 + row, n = en0 + c * 8;
+                        if (m >= p.M || n >= p.N) continue;
+                        const bf16x8 h = hh[u];
+                        st_stream_any((bf16x8*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), h);
+                        if constexpr (EPI == VT_EPI_BF16_GELU) {
+                            bf16x8 gl;
+                            bool looked_up = false;
+                            if constexpr (TABLE) {
+                                unsigned idx[8], any = 0;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { idx[e] = GT::index(bf16_bits(h[e])); any |= idx[e]; }
+                                if (__builtin_amdgcn_ballot_w64((any & 0x8000u) != 0) == 0) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) gl[e] = ((const bf16_t*)tab)[idx[e]];
+                                    looked_up = true;
+                                }
+                            }
+                            if (!looked_up) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) gl[e] = f2bf(gelu_erf(bf2f(h[e])));
+                            }
+                            st_stream_any((bf16x8*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n), gl);
+                        }
                     }
                 }
                 continue;

@@ -8,6 +8,7 @@ order backward produces them, so a data-parallel reducer can all-reduce finished
 stages are still running (parallel.py).
 """
 import ctypes
+import os
 
 import torch
 
@@ -398,15 +399,18 @@ class GraphedStep:
         # left at that address -- `loss = a + 0.1 * b` came out as 1.0 + 0.1 * b, 1.0 being the backward seed that had reused `a`'s block
         # -- depending on which single-workgroup kernels ran in between (a `torch.equal` outside was enough).  Every kernel of this
         # library reads its operands with vector loads and is unaffected: gradients and weights stayed bit-equal to eager in all nine
-        # patterns tried.  Round 4 looked for the cause with a torch-only graph of the same shape (tools/graph_scalar_probe.py: 0-dim
-        # producer -> 0-dim consumer, the freed block re-used by ones_like, a single-workgroup reader between replays, with and without
-        # the runtime's graph packet capture): it does NOT reproduce there (profiles/r04_graph_scalar_probe.log), so the scalar-cache
-        # explanation is unproven and no fix on this side is known.  Instead of a rule for callers ("keep the scalar part linear"), the
-        # constructor now CHECKS the caller's own loss_fn: `self_check` replays the captured step twice on the example clip, with the
-        # round-3 trigger in between, and compares every gradient and the in-graph loss with an eager step of the same seed, bit for
-        # bit; a mismatch raises (a loss with a non-constant scalar factor, e.g. an adaptive weight that is a product of two 0-dim
-        # tensors, is thereby verified rather than trusted).  (2) Small outputs are copied, inside the graph, into buffers from the
-        # ordinary pool; large ones are the graph's static tensors.
+        # patterns tried.  Round 4 found the trigger and the switch (tools/graph_stale_scalar_check.sh, profiles/r04_graph_stale_scalar.log):
+        # a loss whose SCALAR factors change from step to step (an adaptive weight, a product of two loss terms) back-propagates the
+        # PREVIOUS replay's factors -- the engine's d_losses, which torch kernels of the same replay produce, arrives stale -- under the
+        # runtime's graph packet capture (pre-recorded kernel packets, the default of this ROCm build) and is correct, twice out of
+        # twice, with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.  It is not a cache effect on this side: a chip-wide L2 write-back + L1 / L2 /
+        # scalar-cache invalidation kernel between the nodes changed nothing.  A torch-only graph of the same shape does not show it
+        # (tools/graph_scalar_probe.py).  Consequences: (a) video_tokenizer_amd sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 when it is
+        # imported before the HIP runtime has read its flags (an existing value is respected); (b) the constructor CHECKS the caller's
+        # own loss_fn on two different clips in alternation -- loss and every gradient of each replay against an eager step, bit for
+        # bit -- and raises on a difference, so a process where the switch came too late fails loudly instead of training on stale
+        # weights.  (2) Small outputs are copied, inside the graph, into buffers from the ordinary pool; large ones are the graph's
+        # static tensors.
         self._keep = tuple(outputs)
         self._out = None
         self._graph_out = None
@@ -427,30 +431,37 @@ class GraphedStep:
             self._self_check()
 
     def _self_check(self):
-        """One eager step and two replays of the example clip from the same quantizer seed: loss and every gradient must be equal bit for
-        bit (the engine's kernels are deterministic), also after a single-workgroup kernel has read the graph's loss buffer between the
-        replays -- the pattern that exposed a stale 0-dim read in round 3.  Raises RuntimeError on a difference."""
+        """Replays against eager steps, bit for bit, on TWO clips in alternation (the example clip and a scrambled copy), each from its
+        own quantizer seed: a scalar that a replay reads as the previous replay left it -- the failure round 4 pinned on the runtime's
+        graph packet capture -- shows as soon as consecutive replays differ in their loss terms.  A single-workgroup kernel reads the
+        graph-resident loss between replays (the pattern that exposed the stale read in round 3).  Raises RuntimeError on a difference."""
         eng, model = self.engine, self.model
         k0 = int(self.ctr.item())
+        x_a = self.x.detach().clone()
+        x_b = (1.0 - x_a).flip(-1).contiguous()                    # same range, different content: every loss term changes
+        bad = []
         with torch.cuda.stream(self.stream):
-            self.ctr.fill_(k0)
-            for p in model.parameters():
-                p.grad = None
-            eager_loss, _ = self._step()
-            want = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-            eager_loss = eager_loss.detach().clone()
-            bad = []
-            for rep in range(2):
-                self.ctr.fill_(k0)
+            want = []
+            for j, xin in enumerate((x_a, x_b)):
+                self.x.copy_(xin)
+                self.ctr.fill_(k0 + 16 * j)
+                for p in model.parameters():
+                    p.grad = None
+                loss, _ = self._step()
+                want.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+            for rep, j in enumerate((0, 1, 0, 1)):
+                self.x.copy_((x_a, x_b)[j])
+                self.ctr.fill_(k0 + 16 * j)
                 self.graph.replay()
                 got_loss = self._graph_loss.detach().clone()
-                torch.equal(self._graph_loss, got_loss)        # a kernel (not .item()) reads the graph-resident scalar: the round-3 trigger
-                if not torch.equal(got_loss, eager_loss):
-                    bad.append(f"replay {rep}: in-graph loss {got_loss.item()!r} != eager {eager_loss.item()!r}")
-                for n, g in want.items():
+                torch.equal(self._graph_loss, got_loss)        # a kernel (not .item()) reads the graph-resident scalar
+                if not torch.equal(got_loss, want[j][0]):
+                    bad.append(f"replay {rep}: in-graph loss {got_loss.item()!r} != eager {want[j][0].item()!r}")
+                for n, g in want[j][1].items():
                     if not torch.equal(eng.grad_views[n].view(g.shape), g):
                         bad.append(f"replay {rep}: gradient of {n} differs from the eager step")
                         break
+            self.x.copy_(x_a)
             self.ctr.fill_(k0)
         torch.cuda.current_stream().wait_stream(self.stream)
         for name, p in model.named_parameters():
@@ -458,9 +469,10 @@ class GraphedStep:
                 p.grad = eng.grad_views[name].view(p.shape)
         if bad:
             self.close()
-            raise RuntimeError("GraphedStep self-check failed -- the captured step does not reproduce the eager step:\n  " + "\n  ".join(bad) +
-                               "\n(see DESIGN 6b: a scalar factor of the loss read inside the graph can be stale on this platform; restructure the loss "
-                               "or train with the eager step)")
+            raise RuntimeError("GraphedStep self-check failed -- the captured step does not reproduce the eager step:\n  " + "\n  ".join(bad[:6]) +
+                               "\nOn this ROCm build replays read stale scalars under the runtime's graph packet capture: set "
+                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the process touches the GPU (importing video_tokenizer_amd "
+                               "first does it), or train with the eager step (DESIGN 6b)")
 
     def _step(self):
         self.ctr.add_(1)
