@@ -597,7 +597,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
     const vtGemmTN& p = a.p[g];
     const int local = sid - a.tile_start[g];
     const int tiles_q = (p.q_lim + TN_ - 1) / TN_;
-    const int p0 = (local / tiles_q) * TM, q0 = (local % tiles_q) * TN_;
+    // tiles walk in groups of 4 p-rows, p fastest: an XCD's round of 32 consecutive tiles is a 4 x 8 (or 8 x 4) block of the output,
+    // i.e. 12 operand panels instead of the 18 a row-major walk gives a wide problem (fc2's 4 x 16 tiles: 2 x 16 per round)
+    const int tiles_p = (p.p_lim + TM - 1) / TM;
+    const int grp4 = local / (4 * tiles_q), rem4 = local - grp4 * 4 * tiles_q;
+    const int rows4 = min(4, tiles_p - grp4 * 4);
+    const int p0 = (grp4 * 4 + rem4 % rows4) * TM, q0 = (rem4 / rows4) * TN_;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
 
@@ -711,7 +716,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192p_kernel(const TN192Args a) 
     const vtGemmTN& p = a.p[g];
     const int local = sid - a.tile_start[g];
     const int tiles_q = (p.q_lim + TN_ - 1) / TN_;
-    const int p0 = (local / tiles_q) * TM, q0 = (local % tiles_q) * TN_;
+    // tiles walk in groups of 4 p-rows, p fastest: an XCD's round of 32 consecutive tiles is a 4 x 8 (or 8 x 4) block of the output,
+    // i.e. 12 operand panels instead of the 18 a row-major walk gives a wide problem (fc2's 4 x 16 tiles: 2 x 16 per round)
+    const int tiles_p = (p.p_lim + TM - 1) / TM;
+    const int grp4 = local / (4 * tiles_q), rem4 = local - grp4 * 4 * tiles_q;
+    const int rows4 = min(4, tiles_p - grp4 * 4);
+    const int p0 = (grp4 * 4 + rem4 % rows4) * TM, q0 = (rem4 / rows4) * TN_;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
 

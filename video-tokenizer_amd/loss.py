@@ -219,6 +219,7 @@ class VQLPIPSWithDiscriminator(nn.Module):
                                                       input_size=input_spatial_size, temporal_patch_size=disc_tran_temporal_patch_size,
                                                       patch_size=disc_tran_patch_size, in_channels=disc_in_channels, frame_num=frame_num)
         self.disc_type = "3d"
+        self.spectral_norm = bool(spectral_norm)
         if spectral_norm:
             _spectral_normalise(self.discriminator)
         self.discriminator_iter_start = disc_start
