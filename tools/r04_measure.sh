@@ -49,4 +49,6 @@ for k, c in out.items():
 json.dump(res, open("$R/profiles/r04_pmc_gemm_tn192.json", "w"), indent=1)
 print(json.dumps(res)[:1200])
 PY
-ls -la $O profiles/r04_*
+# only gpurun_out/ travels back from the GPU box: leave a copy of every record written above there
+mkdir -p $O/profiles && cp profiles/r04_bench.json profiles/r04_bench_under_rocprofv3.json profiles/r04_kernel_stats.csv profiles/r04_pmc_traffic_gemm_nt192.json profiles/r04_pmc_mfma_busy_step.json profiles/r04_pmc_gemm_tn192.json $O/profiles/ 2>/dev/null
+ls -la $O $O/profiles
