@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the attention kernels only (tools/attn_bench.py 3): issue / wait / co-execution / LDS counters.
-# usage: bash tools/pmc_attn.sh <tag>   (set VT_ATTN_PIPE=1 outside for the software-pipelined forward).  GPU box, repo root.
+# usage: bash tools/pmc_attn.sh <tag>   GPU box, repo root.  Output keyed per kernel (attn_fwd_kernel<64, false>, attn_bwd_dq_kernel<...>, attn_bwd_dkv_kernel<...>).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-attn}

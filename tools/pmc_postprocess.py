@@ -39,8 +39,9 @@ def busy(counters, trace, nsteps, out, note, ghz=2.1):
         d = dur.get(r["Dispatch_Id"])
         if d is None:
             continue
-        k = d[1].split("(")[0][-60:] if not d[1].startswith("void") else d[1].split("(anonymous namespace)::")[-1].split("(")[0]
-        a = agg["void " + k if d[1].startswith("void") else k]
+        k = d[1].replace("(anonymous namespace)::", "")
+        k = (k[5:] if k.startswith("void ") else k).split("(")[0][-64:]
+        a = agg[k]
         a[0] += float(r["Counter_Value"])
         a[1] += d[0]
         a[2] += 1
