@@ -146,10 +146,31 @@ def committed_profile(kind):
     return None
 
 
+def torch_yardstick(batch):
+    """The same step written with stock PyTorch-ROCm ops (nn.Linear / LayerNorm / SDPA / GELU under autocast bf16) on an MI355X of this
+    pool: tools/torch_yardstick.py, measured by tools/torch_yardstick.sh next to this script and committed under profiles/.  Context
+    for `value`, not a baseline in BASELINE.md's sense (the reference publishes no throughput): `vs_baseline` stays null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_torch_yardstick.jsonl")), reverse=True):
+        out = {}
+        with open(path) as f:
+            for line in f:
+                try:
+                    d = json.loads(line)
+                except ValueError:
+                    continue
+                if d.get("clips_per_gpu") == batch and "clips_per_s" in d:
+                    out.setdefault("torch_compile_clips_per_s" if d.get("compiled") else "eager_clips_per_s", d["clips_per_s"])
+        if out:
+            out["source"] = os.path.relpath(path, ROOT)
+            return out
+    return None
+
+
 def measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from PMC counters (cannot be collected inside this process):
     the rocprofv3 passes of tools/pmc_traffic.sh, committed under profiles/."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None
     with open(path) as f:
@@ -533,6 +554,8 @@ def main():
                 res["roofline"]["mfma_busy_step"] = committed_profile("mfma_busy")
             except Exception as e:  # noqa: BLE001
                 res["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None, "error": repr(e)}
+        if a.config == "B" and not a.gan and a.optimizer == "none":
+            res["stock_pytorch_same_gpu"] = torch_yardstick(B)
         if not a.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (other ranks would sit in teardown meanwhile)
             try:
                 res["cpu_baseline"] = cpu_baseline(c)

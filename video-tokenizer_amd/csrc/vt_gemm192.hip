@@ -24,6 +24,36 @@ constexpr bool kStore16 = false;
 constexpr bool kStore16 = true;
 #endif
 
+// Diagnostic build only (-DVT_GEMM_STAMPS, tools/gemm_stamps.sh): s_memtime stamps around the segments of one OUTPUT tile of the NT kernel,
+// summed per wave: 0 main loop | 1 barrier + next tile's K-tile 0 issued | 2 accumulators -> LDS image | 3 barrier | 4 read-back + global stores |
+// 5 barrier, K-tiles 1-2 issued, wait for K-tile 0, barrier | 6 fragments of K-tile 0 | 7 output tiles.  Read the shares, not the run time.
+#ifdef VT_GEMM_STAMPS
+__device__ unsigned long long g_nt_stamps[256][8][8];
+#define VT_GSTAMP_DECL unsigned long long gs_t = __builtin_amdgcn_s_memtime(), gs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define VT_GSTAMP(i)                                                     \
+    {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long gs_n = __builtin_amdgcn_s_memtime();    \
+        gs_acc[i] += gs_n - gs_t;                                        \
+        gs_t = gs_n;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    }
+#define VT_GSTAMP_FLUSH                                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)                     \
+        for (int i_ = 0; i_ < 8; ++i_) g_nt_stamps[blockIdx.x][threadIdx.x >> 6][i_] = gs_acc[i_]
+#else
+#define VT_GSTAMP_DECL
+#define VT_GSTAMP(i)
+#define VT_GSTAMP_FLUSH
+#endif
+
+// -DVT_GEMM_RESIDUAL_IN_LOOP (A/B builds only): the fp32 epilogue of rounds 1-3, one residual load per trip of its store loop
+#ifdef VT_GEMM_RESIDUAL_IN_LOOP
+constexpr bool kResidualFirst = false;
+#else
+constexpr bool kResidualFirst = true;
+#endif
+
 namespace {
 
 constexpr int TM = 192, TN_ = 192, TK = 64;
@@ -125,7 +155,7 @@ __device__ __forceinline__ void nt192_stage_piece(const bf16_t* a_panel, const b
 template <int EPI, int WN>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args a) {
     using G = NTGeo<WN>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     const vtGemmNT& p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -149,9 +179,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     // ((row>>1)&7) does not depend on the 16-row fragment index (16 rows = 8 swizzle periods), so fragment i sits at
     // +i*2048 bytes: an instruction immediate.
     const int arow = wm * 96 + fr, brow = wn * 48 + fr;
-    const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4), a_off1 = arow * 128 + (((4 + fq) ^ ((arow >> 1) & 7)) << 4);
+    // k-step 1 is chunk 4 + fq: (4 + fq) ^ s = (fq ^ s) ^ 4, i.e. the k-step-0 ADDRESS with bit 6 flipped (ring slots and operand images are
+    // multiples of 128 bytes) -- formed per K-tile from the k-step-0 address, so only two lane offsets live across the main loop.
+    const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4);
     const unsigned b_off0 = G::OPA + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
-    const unsigned b_off1 = G::OPA + brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4);
+    static_assert(G::OPA % 128 == 0 && G::STAGE % 128 == 0, "k-step 1 = k-step 0 ^ 64");
 
     // ---- software pipeline across K-tiles -------------------------------------------------------------------------
     // Tile t is multiplied out of a REGISTER set while the 18 fragment reads of tile t+1 are issued between its MFMA
@@ -175,7 +207,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     }
 #define VT_STEP(Ca0, Cb0, Ca1, Cb1, Na0, Nb0, Na1, Nb1, nb, pf)                                                      \
     {                                                                                                                \
-        const unsigned na0 = (nb) + a_off0, na1 = (nb) + a_off1, nb0 = (nb) + b_off0, nb1 = (nb) + b_off1;           \
+        const unsigned na0 = (nb) + a_off0, na1 = na0 ^ 64u, nb0 = (nb) + b_off0, nb1 = nb0 ^ 64u;                   \
         if (pf) { VT_DSR(Nb0[0], nb0, 0); VT_DSR(Nb0[1], nb0, 2048); }                                               \
         VT_ROW(acc[0], Cb0, Ca0[0]);                                                                                 \
         if (pf) { VT_DSR(Nb0[2], nb0, 4096); VT_DSR(Na0[0], na0, 0); }                                               \
@@ -207,10 +239,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     unsigned poff[G::P];
     const bf16_t *Apanel, *Bpanel;   // wave-uniform: rows m0.. of A / n0.. of B, K-tile 0
     int m0, n0;
+    bool poff_full = false;          // poff holds the offsets of a tile that lies fully inside the matrix (no row is clamped): the same for every such tile
     auto set_tile = [&](int it) {
         const int sid = xcd_remap(it, nwg);
         m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * G::TNW;
-        nt192_piece_offsets<WN>(p.lda, m0, p.M, p.ldb, n0, p.N, tid, poff);
+        const bool full = m0 + TM <= p.M && n0 + G::TNW <= p.N;
+        if (!(full && poff_full)) {
+            int tid_s = tid;
+            asm volatile("" : "+v"(tid_s));  // opaque: the row / chunk terms of the offsets are recomputed when needed instead of living (spilled) across the main loop
+            nt192_piece_offsets<WN>(p.lda, m0, p.M, p.ldb, n0, p.N, tid_s, poff);
+            poff_full = full;
+        }
         Apanel = A + (int64_t)m0 * p.lda;
         Bpanel = B + (int64_t)n0 * p.ldb;
     };
@@ -245,24 +284,38 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     if (a.dbg >= 8 && ((blockIdx.x >> 3) & 1))          // timing experiment (vtGemmNT.tile 8..15): every other CU of an XCD starts 1..8 us late
         for (int i = 0; i < a.dbg - 7; ++i) __builtin_amdgcn_s_sleep(32);
     constexpr bool PERSIST = WN == 4;   // the 192x96 experiment stays one tile per workgroup
+    VT_GSTAMP_DECL;
     for (int it = blockIdx.x; it < nwg; it = PERSIST ? it + (int)gridDim.x : nwg) {
+#ifdef VT_GEMM_STAMPS
+    gs_acc[7] += 1;
+    if (it == (int)blockIdx.x) gs_t = __builtin_amdgcn_s_memtime();
+#endif
     // K-tile 0 of this output tile is already in flight (issued above, or before the previous tile's epilogue)
-    if (it != (int)blockIdx.x) __syncthreads();       // the previous epilogue's LDS image (slots 0-1) has been read back
+    // (zeroed by instructions with an inline constant: as plain C++ the compiler keeps a zero register PAIR alive across the whole
+    // persistent loop to copy from, and spills it in the instantiations that sit at the register limit)
     f32x4 acc[6][3];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 3; ++j) {
+            typedef __attribute__((ext_vector_type(2))) float f32x2_;
+            f32x2_ lo, hi;
+            asm volatile("v_mov_b64 %0, 0" : "=v"(lo));
+            asm volatile("v_mov_b64 %0, 0" : "=v"(hi));
+            acc[i][j] = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+    if (it != (int)blockIdx.x) __syncthreads();       // the previous epilogue's LDS image (slots 0-1) has been read back
     if (nt > 1) issue_tile(1);
     if (G::NST > 2 && nt > 2) issue_tile(2);
     if (G::NST > 2 && nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::P) : "memory");
     else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::P) : "memory");
     else wait_vmcnt0();
     raw_barrier();
+    VT_GSTAMP(5);
     bf16x8 xa0[6], xb0[3], xa1[6], xb1[3], ya0[6], yb0[3], ya1[6], yb1[3];
     {   // fragments of tile 0
         const unsigned s0 = sbase + slot_of(0) * G::STAGE;
-        const unsigned na0 = s0 + a_off0, na1 = s0 + a_off1, nb0 = s0 + b_off0, nb1 = s0 + b_off1;
+        const unsigned na0 = s0 + a_off0, na1 = na0 ^ 64u, nb0 = s0 + b_off0, nb1 = nb0 ^ 64u;
         VT_DSR(xb0[0], nb0, 0); VT_DSR(xb0[1], nb0, 2048); VT_DSR(xb0[2], nb0, 4096);
         VT_DSR(xa0[0], na0, 0); VT_DSR(xa0[1], na0, 2048); VT_DSR(xa0[2], na0, 4096);
         VT_DSR(xa0[3], na0, 6144); VT_DSR(xa0[4], na0, 8192); VT_DSR(xa0[5], na0, 10240);
@@ -273,6 +326,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
+    VT_GSTAMP(6);
     for (int t = 0;;) {
         // tile t from set X, prefetch tile t+1 into set Y.  The prefetch is unconditional (branch-free tile body, one
         // body per register set): after the last tile it re-reads a valid, quiescent LDS buffer into the unused set.
@@ -303,6 +357,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     // every wave is done with the ring: start the next output tile's K-tile 0 into slot 2 (the epilogue below only uses
     // slots 0-1), then write this tile out
     const int em0 = m0, en0 = n0;
+    VT_GSTAMP(0);
     raw_barrier();
     if constexpr (PERSIST) {
         if (it + (int)gridDim.x < nwg) {
@@ -310,6 +365,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             if (a.dbg != 1) issue_tile(0);
         }
     }
+    VT_GSTAMP(1);
 
     if constexpr (EPI != VT_EPI_F32) {
         if ((p.N & 3) == 0) {
@@ -355,7 +411,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     const f32x4 v = acc[i][j] + b4[j];
                     *(bf16x4*)(smem + (wm * 96 + i * 16 + fr_e) * STRIDE + (wn * 12 + j * 4 + fq_e) * 8) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 }
+            VT_GSTAMP(2);
             __syncthreads();
+            VT_GSTAMP(3);
             if constexpr (EPI == VT_EPI_BF16_DGELU) {
                 // a thread keeps ONE 4-column group and walks the rows (48 lanes cover a 384-B row, the rest of the wave the
                 // next row), so the column sums of the rounded output -- the bias gradient of the Linear whose
@@ -398,21 +456,22 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                 constexpr int UPR16 = G::TNW / 8;                        // 16-B units per tile row
                 constexpr int NIT16 = TM * UPR16 / G::THREADS, RB16 = 3;
                 static_assert(NIT16 % RB16 == 0, "read-back batches");
+                // WN = 4: a thread's 9 pieces are 3 row passes of 64 rows x 3 column groups of 64.  Lanes 8r..8r+7 of a wave instruction cover one
+                // 128-byte line of row r (8 full lines per instruction), and every address is one per-thread base plus compile-time terms (the
+                // slot / 24 mapping, kept for the 192x96 experiment, costs ~10 integer instructions per piece).
+                auto piece_row = [&](int u) { if constexpr (WN == 4) return (tid_e >> 3) + (u / 3) * 64; else return (u * G::THREADS + tid_e) / UPR16; };
+                auto piece_col = [&](int u) { if constexpr (WN == 4) return (tid_e & 7) * 8 + (u % 3) * 64; else return ((u * G::THREADS + tid_e) % UPR16) * 8; };
+                auto piece_src = [&](int u) { return (const char*)smem + piece_row(u) * STRIDE + piece_col(u) * 2; };     // 8-byte aligned (row stride 392)
 #pragma unroll 1
                 for (int it0 = 0; it0 < NIT16; it0 += RB16) {
                     bf16x8 hh[RB16];
 #pragma unroll
                     for (int u = 0; u < RB16; ++u) {
-                        const int slot = (it0 + u) * G::THREADS + tid_e;
-                        const int row = slot / UPR16, c = slot - row * UPR16;
-                        const char* src = smem + row * STRIDE + c * 16;     // 8-byte aligned (row stride 392)
-                        hh[u] = cat4(*(const bf16x4*)src, *(const bf16x4*)(src + 8));
+                        hh[u] = cat4(*(const bf16x4*)piece_src(it0 + u), *(const bf16x4*)(piece_src(it0 + u) + 8));
                     }
 #pragma unroll
                     for (int u = 0; u < RB16; ++u) {
-                        const int slot = (it0 + u) * G::THREADS + tid_e;
-                        const int row = slot / UPR16, c = slot - row * UPR16;
-                        const int m = em0 + row, n = en0 + c * 8;
+                        const int m = em0 + piece_row(it0 + u), n = en0 + piece_col(it0 + u);
                         if (m >= p.M || n >= p.N) continue;
                         const bf16x8 h = hh[u];
                         st_stream_any((bf16x8*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), h);
@@ -437,6 +496,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                         }
                     }
                 }
+                VT_GSTAMP(4);
+                if (it + (int)gridDim.x >= nwg) { VT_GSTAMP_FLUSH; }
                 continue;
             }
             // read-back in batches of RB image reads followed by their stores: with one read in flight per store (the compiler's order for
@@ -483,6 +544,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
         }
     }
     const RowMap omap{p.omap.grp, p.omap.stride, p.omap.off};
+    // (the lane's fragment coordinates again from an opaque copy of the thread id: the kernel-entry `fr` / `fq` would otherwise stay live -- spilled -- across the main loop)
+    int tid_x = tid;
+    asm volatile("" : "+v"(tid_x));
+    const int fr_x = tid_x & 15, fq_x = (tid_x & 63) >> 4;
     if constexpr (EPI == VT_EPI_F32 && WN == 4) {
         if ((p.N & 3) == 0) {
             // fp32 outputs leave through LDS as well, 96 rows (one wave row) at a time: [96][192] fp32 image, row stride
@@ -493,12 +558,39 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
             f32x4 b4[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int n = en0 + wn * 48 + j * 16 + fq * 4;
+                const int n = en0 + wn * 48 + j * 16 + fq_x * 4;
                 b4[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 if (hf) __syncthreads();
+                // The residual rows of this half are requested FIRST, all NU of them: their latency runs under the staging writes and the
+                // barrier.  (One load per trip of a rolled loop left 8 KiB in flight per CU -- 2 MB on the chip -- and every trip paid a full
+                // memory round trip: the fp32 epilogue cost 11 us more than the bf16 one on the same product.)
+                constexpr int NU = 96 * 48 / G::THREADS;
+                // output row of tile row d without a division per piece: the tile starts at group q0, row r0 of the row map, and with
+                // grp >= 192 it crosses at most one group boundary (other maps take the rolled loop below)
+                const bool cheap_map = kResidualFirst && (omap.grp == 0 || omap.grp >= TM);
+                const int q0 = omap.grp ? em0 / omap.grp : 0, r0 = omap.grp ? em0 - q0 * omap.grp : em0;
+                auto orow_of = [&](int d) -> int64_t {
+                    const int r = r0 + d;
+                    if (omap.grp == 0) return r;
+                    const bool wrap = r >= omap.grp;
+                    return (int64_t)(q0 + (wrap ? 1 : 0)) * omap.stride + omap.off + (wrap ? r - omap.grp : r);
+                };
+                constexpr int RBF = 3;             // pieces per batch: one batch of loads is in flight while the previous one is added and stored
+                static_assert(NU % RBF == 0, "residual batches");
+                auto load_res = [&](int u) -> f32x4 {
+                    const int slot = u * G::THREADS + tid_x;
+                    const int row = slot / 48, c = slot - row * 48;
+                    const int m = em0 + hf * 96 + row, n = en0 + c * 4;
+                    return (p.residual && m < p.M && n < p.N) ? *(const f32x4*)(p.residual + orow_of(hf * 96 + row) * p.ldr + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                };
+                f32x4 res[RBF];
+                if (cheap_map) {
+#pragma unroll
+                    for (int u = 0; u < RBF; ++u) res[u] = load_res(u);
+                }
                 if (wm == hf) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
@@ -506,13 +598,42 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                         for (int j = 0; j < 3; ++j) {
                             f32x4 v = acc[i][j] + b4[j];
                             if (p.round_bf16) v = (f32x4){round_bf16(v[0]), round_bf16(v[1]), round_bf16(v[2]), round_bf16(v[3])};
-                            *(f32x4*)(smem + (i * 16 + fr) * FSTRIDE + (wn * 48 + j * 16 + fq * 4) * 4) = v;
+                            *(f32x4*)(smem + (i * 16 + fr_x) * FSTRIDE + (wn * 48 + j * 16 + fq_x * 4) * 4) = v;
                         }
                 }
                 __syncthreads();
+                if (cheap_map) {
+#pragma unroll
+                    for (int u0 = 0; u0 < NU; u0 += RBF) {
+                        f32x4 nxt[RBF];
+                        if (u0 + RBF < NU) {
+#pragma unroll
+                            for (int u = 0; u < RBF; ++u) nxt[u] = load_res(u0 + RBF + u);
+                        }
+#pragma unroll
+                        for (int uu = 0; uu < RBF; ++uu) {
+                            const int slot = (u0 + uu) * G::THREADS + tid_x;
+                            const int row = slot / 48, c = slot - row * 48;
+                            const int m = em0 + hf * 96 + row, n = en0 + c * 4;
+                            if (m >= p.M || n >= p.N) continue;
+                            f32x4 v = *(const f32x4*)(smem + row * FSTRIDE + c * 16);
+                            const int64_t orow = orow_of(hf * 96 + row);
+                            if (p.residual) v += res[uu];
+                            if (p.rowmod) v += *(const f32x4*)(p.rowmod + (int64_t)(m % p.rowmod_period) * p.N + n);
+                            if (p.out_scale != 0.f) v *= p.out_scale;
+                            *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+                            if (p.out2) st_stream((bf16x4*)((bf16_t*)p.out2 + orow * p.ldo2 + n), (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])});
+                        }
+                        if (u0 + RBF < NU) {
+#pragma unroll
+                            for (int u = 0; u < RBF; ++u) res[u] = nxt[u];
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll 1
-                for (int u = 0; u < 96 * 48 / G::THREADS; ++u) {
-                    const int slot = u * G::THREADS + tid;
+                for (int u = 0; u < NU; ++u) {
+                    const int slot = u * G::THREADS + tid_x;
                     const int row = slot / 48, c = slot - row * 48;
                     const int m = em0 + hf * 96 + row, n = en0 + c * 4;
                     if (m >= p.M || n >= p.N) continue;
@@ -530,11 +651,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const int m = em0 + wm * 96 + i * 16 + fr;
+        const int m = em0 + wm * 96 + i * 16 + fr_x;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int n = en0 + wn * 48 + j * 16 + fq * 4;
+            const int n = en0 + wn * 48 + j * 16 + fq_x * 4;
             if (n >= p.N) continue;
             nt_epilogue<EPI>(p, omap, m, n, acc[i][j]);
         }
@@ -584,7 +705,7 @@ __device__ __forceinline__ bf16x8 frag_tn192(const char* lds, int col, int kb, i
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -703,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192_kernel(const TN192Args a) {
 // A fragment's two reads differ by an immediate (rows +4 = +1536 B, swizzle unchanged: f(row) reads row bits 1 and 3), the
 // k-half by another (+32 rows = +12288 B), so a wave carries 9 per-lane base offsets (6 A + 3 B column groups).
 __global__ __launch_bounds__(512, 2) void gemm_tn192p_kernel(const TN192Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -939,6 +1060,12 @@ static hipError_t allow_lds_nt() {
     return hipFuncSetAttribute((const void*)gemm_nt192_kernel<EPI, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                NTGeo<WN>::NST * NTGeo<WN>::STAGE + (WN == 4 ? GeluTab<EPI>::BYTES : 0));
 }
+
+#ifdef VT_GEMM_STAMPS
+extern "C" int vt_gemm_nt_stamps(unsigned long long* host_out) {   // diagnostic build only: 256 x 8 x 8 counters
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(g_nt_stamps)) == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+#endif
 
 int vt_gemm192_init() {
     // more dynamic LDS than the 64 KiB default: opt in once per kernel

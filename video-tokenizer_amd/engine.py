@@ -364,8 +364,9 @@ class GraphedStep:
     """The whole forward + loss + backward of a fixed geometry captured ONCE as a hipGraph (torch.cuda.CUDAGraph) and replayed.
 
     Why: at the reference's own recipe -- global batch 8 on 8 GPUs = ONE clip per GPU (scripts/train_larp_tokenizer_reproduce.sh:8,
-    trainers/base_trainer.py:316) -- the GPU needs 3-4 ms per step and the host ~5 ms to enqueue its ~900 launches: the step is
-    host-bound.  A replay costs one launch.  What makes the step capturable: the engine never allocates or synchronises; the weight
+    trainers/base_trainer.py:316) -- the host spends ~5 ms per step enqueueing ~900 launches (measured 5.2 ms next to 7.75 ms of GPU
+    time): a replay costs the host 0.3-0.4 ms and frees it for the loader and the optimizer, the GPU time per step stays
+    what it was.  What makes the step capturable: the engine never allocates or synchronises; the weight
     re-pack runs inside the graph; the stochastic quantizer's per-call seed word is a DEVICE counter incremented in the graph
     (vt_vq_forward_ctr), giving the same noise sequence as eager calls; gradients land in the engine's flat buffer, whose views
     the parameters' .grad keep pointing at.  The optimizer step stays outside (FusedAdam.step() is 4-5 launches).
