@@ -439,6 +439,19 @@ int vt_tokenizer_set_seed_counter(vtTokenizer* tk, const uint32_t* seed_counter)
  * larger batch and, re-rounded to bf16 layer after layer, differ from them at the bf16 noise level (~5e-3 relative on the deepest
  * layers) instead of ~1e-6: switch it off where bit-stable gradients across batch sizes matter more than the ~8 % it buys. */
 int vt_tokenizer_set_split_k(vtTokenizer* tk, int32_t on);
+/* Data-parallel runs (ABI 7).  The weight gradients of four consecutive blocks are produced by ONE grouped launch, so a group's gradients are
+ * final -- and DistributedDataParallel's bucketed all-reduce of them (trainers/base_trainer.py:388) can start -- only there; by default the
+ * encoder's blocks 3..0 finish at the very end of backward and their 113 MB (config B) are reduced with nothing left to overlap.  n > 0: the
+ * encoder's blocks below n flush block by block (n = 3: groups 3-2 | 1 | 0), leaving one block's gradients for the exposed tail at the price
+ * of three launches that do not fill whole rounds of the chip.  Bit-identical gradients.  parallel.DataParallelTokenizer sets n = 3. */
+int vt_tokenizer_set_wgrad_tail(vtTokenizer* tk, int32_t n);
+/* Data-parallel runs (ABI 7).  side != NULL: the grouped weight-gradient launches and the partial-sum reductions of the same blocks are
+ * enqueued on `side` instead of the caller's stream, behind an event of the caller's stream; the caller's stream waits for them at the last
+ * stage of backward (and before it rewrites an operand buffer a pending group still reads).  They are off the critical path of backward, and
+ * while a collective's workgroups hold CUs the exact-fit GEMM launches of the main stream leave most of the chip idle in their extra round:
+ * an independent stream fills it.  A consumer of a finished gradient slice (final_through of vt_tokenizer_backward) must wait for BOTH
+ * streams.  Same kernels on the same operands: bit-identical gradients.  NULL restores the single-stream schedule.  Not capturable. */
+int vt_tokenizer_set_wgrad_stream(vtTokenizer* tk, vtStream side);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);

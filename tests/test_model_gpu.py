@@ -208,6 +208,80 @@ def test_gradient_buckets_run_under_later_backward_stages_rccl():
             dist.destroy_process_group()
 
 
+def test_weight_gradient_tail_schedule_is_bit_identical():
+    """vt_tokenizer_set_wgrad_tail (what DataParallelTokenizer switches on): the encoder's first blocks flush their weight gradients in
+    groups 3-2 | 1 | 0 instead of one group of four, so the last slice to become final is one block's.  Same kernels, same operands:
+    every gradient equals the default schedule's bit for bit, for every n, and the finished-stage counter still reaches the last stage."""
+    cfg = O.make_cfg("tiny", encoder_depth=6, decoder_depth=2)
+    model, _ = build(cfg, seed=11)
+    model.train()
+    x = torch.from_numpy(gen.video_clips(2, cfg["frame_num"], cfg["input_size"], 77)).cuda()
+    w = torch.from_numpy(gen.normal(tuple(x.shape), 78)).cuda()
+
+    def grads(n):
+        model._engine.set_wgrad_tail(n)
+        for p in model.parameters():
+            p.grad = None
+        out = model(x)
+        ((out["pred_frames"] * w).sum() + 0.7 * out["loss_q"]).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    base = grads(0)
+    assert len(base) > 60 and all(torch.isfinite(g).all() for g in base.values())
+    for n in (1, 3, 6, 9):
+        got = grads(n)
+        assert got.keys() == base.keys()
+        bad = [k for k in base if not torch.equal(got[k], base[k])]
+        assert not bad, (n, bad[:5])
+    model._engine.set_wgrad_tail(0)
+
+
+@pytest.mark.parametrize("name,over,clips", [("tiny", dict(encoder_depth=11, decoder_depth=5), 2), ("C", {}, 2)])
+def test_weight_gradients_on_their_own_stream_are_bit_identical(name, over, clips):
+    """vt_tokenizer_set_wgrad_stream (what DataParallelTokenizer switches on): the grouped weight-gradient launches and the partial-sum
+    reductions run on a second stream, ordered against the backward's critical path by events (fork at every flush, a wait before a
+    gradient set is rewritten, a join at the last stage).  Same kernels, same operands: every gradient of three consecutive steps equals
+    the single-stream schedule's bit for bit -- also with the block-by-block tail and with an unrelated kernel keeping the side stream
+    busy, which shifts every ordering that is not enforced."""
+    cfg = O.make_cfg(name, **over)
+    model, _ = build(cfg, seed=13)
+    model.train()
+    xs = [torch.from_numpy(gen.video_clips(clips, cfg["frame_num"], cfg["input_size"], 90 + i)).cuda() for i in range(3)]
+    w = torch.from_numpy(gen.normal(tuple(xs[0].shape), 99)).cuda()
+    eng = model._engine
+    side = torch.cuda.Stream()
+    ballast = torch.randn(4096, 4096, device="cuda")
+
+    def run(stream, tail, busy):
+        eng.set_wgrad_stream(stream)
+        eng.set_wgrad_tail(tail)
+        res = []
+        for x in xs:
+            for p in model.parameters():
+                p.grad = None
+            out = model(x)
+            loss = (out["pred_frames"] * w).sum() + 0.7 * out["loss_q"]
+            if busy:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        ballast @ ballast                 # the side stream is late: whatever is not ordered by an event shows
+            loss.backward()
+            res.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        torch.cuda.synchronize()
+        return res
+
+    base = run(None, 0, False)
+    assert all(torch.isfinite(g).all() for g in base[-1].values())
+    for stream, tail, busy in ((side, 0, False), (side, 3, False), (side, 3, True), (side, 0, True)):
+        got = run(stream, tail, busy)
+        for i, (a, b) in enumerate(zip(got, base)):
+            bad = [k for k in b if not torch.equal(a[k], b[k])]
+            assert not bad, (tail, busy, i, bad[:5])
+    eng.set_wgrad_stream(None)
+    eng.set_wgrad_tail(0)
+
+
 def test_config_A_full_depth_matches_oracle():
     """BASELINE configs[0]: cfgs/larp_tokenizer.yaml geometry on 2x64x64 clips, bs=1, full 12+12 depth (L = 16 + 1024 =
     1040: not a multiple of any tile).  Forward + a few gradients against the CPU oracle (fp32 reference semantics AND

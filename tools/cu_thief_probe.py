@@ -3,11 +3,15 @@
 RCCL's all-reduce runs as persistent workgroups (one per channel) next to the backward of the step (parallel.GradReducer, side
 stream).  Such a workgroup cannot share a CU with a 192x192 GEMM workgroup (LDS and registers are full), so while it runs the
 GEMMs of the step see 256 - n CUs.  tools/probes/cu_thief.hip holds n CUs the same way (n workgroups x 256 threads x 96 KiB LDS,
-spinning on the real-time counter); this script runs bench.py's step with the thief on a side stream for the WHOLE step (the upper
-bound: an all-reduce covers only part of the backward) and for n = 0, 4, 8, 16, 32, 64 prints ms per step.
+spinning on the real-time counter).  This script runs bench.py's step next to it
+
+  * for the WHOLE step (the upper bound), n = 4 ... 64, single-stream schedule;
+  * and in BURSTS: a thief of `burst_ms` started behind the forward of every step -- a collective resident for that long inside the
+    backward -- under the single-stream schedule and under the data-parallel one (weight gradients on their own stream, block-by-block
+    tail: engine.set_wgrad_stream / set_wgrad_tail, what parallel.DataParallelTokenizer switches on).
 
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/cu_thief.hip -o tools/probes/_bin/libcu_thief.so   # in the dev container
-    python3 tools/cu_thief_probe.py [clips]"""
+    python3 tools/cu_thief_probe.py [clips] [burst_ms]"""
 import ctypes
 import os
 import sys
@@ -21,6 +25,7 @@ import video_tokenizer_amd as vt  # noqa: E402
 from video_tokenizer_amd.config import geometry, model_spec  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+BURST = float(sys.argv[2]) if len(sys.argv) > 2 else 3.5
 thief = ctypes.CDLL(os.path.join(R, "tools", "probes", "_bin", "libcu_thief.so"))
 thief.thief_launch.restype = ctypes.c_int
 thief.thief_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
@@ -31,44 +36,66 @@ model = vt.make(model_spec(c, stochastic=True))
 with torch.no_grad():
     torch.nn.init.xavier_uniform_(model.final_layer.linear.weight)
 model = model.cuda().train()
+eng = model._engine
 x = torch.from_numpy(vt.config.synthetic_clips(B, c["frame_num"], c["input_size"], 100)).cuda()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
-side = torch.cuda.Stream()
+thief_stream = torch.cuda.Stream()
+wg_stream = torch.cuda.Stream()
 
 
-def step():
+def step(burst_cus=0):
     out = model(x)
     loss = (out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_q"]
     for p in model.parameters():
         p.grad = None
+    if burst_cus:
+        thief_stream.wait_stream(torch.cuda.current_stream())       # the thief arrives when the forward is done, like the first bucket's collective
+        assert thief.thief_launch(burst_cus, BURST, sink.data_ptr(), thief_stream.cuda_stream) == 0
     loss.backward()
 
 
-def timed(n_cus, steps=10):
+def timed(hold_cus=0, burst_cus=0, steps=10):
     for _ in range(3):
-        step()
+        step(burst_cus)
     torch.cuda.synchronize()
-    if n_cus:
+    if hold_cus:
         # the thief outlives the timed steps (bounded: 0.6 s) and is released by its own clock; start it first so it is resident
-        rc = thief.thief_launch(n_cus, 600.0, sink.data_ptr(), side.cuda_stream)
-        assert rc == 0, rc
+        assert thief.thief_launch(hold_cus, 600.0, sink.data_ptr(), thief_stream.cuda_stream) == 0
         time.sleep(0.02)
-    t0 = time.perf_counter()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
-        step()
+        step(burst_cus)
     e1.record()
     e1.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    torch.cuda.synchronize()          # the thief's 0.6 s run out
+    torch.cuda.synchronize()          # the thief's time runs out
     assert ms * steps < 550.0, "the timed steps outlived the thief: lower `steps`"
     return ms
 
 
-base = timed(0)
-print(f"{B} clips per GPU, forward + backward, ms per step (10 steps, events): no thief {base:.2f}", flush=True)
-for n in (4, 8, 16, 32, 64):
-    ms = timed(n)
-    again = timed(0)
-    print(f"  {n:3d} CUs held for the whole step: {ms:.2f} ms (+{100 * (ms / base - 1):.1f} %; CUs lost {100 * n / 256:.1f} %)   no thief again: {again:.2f}", flush=True)
+def schedule(two_streams):
+    eng.set_wgrad_stream(wg_stream if two_streams else None)
+    eng.set_wgrad_tail(3 if two_streams else 0)
+
+
+schedule(False)
+base = timed()
+print(f"{B} clips per GPU, forward + backward, ms per step (10 steps, events).  single-stream schedule, no thief: {base:.2f}", flush=True)
+for n in (4, 16, 64):
+    ms = timed(hold_cus=n)
+    print(f"  {n:3d} CUs held for the whole step: {ms:.2f} ms (+{100 * (ms / base - 1):.1f} %; CUs lost {100 * n / 256:.1f} %)", flush=True)
+print(f"bursts: a thief of {BURST} ms behind the forward of every step (a collective resident that long inside the backward)", flush=True)
+for rnd in range(2):
+    for two in (False, True):
+        schedule(two)
+        name = "weight gradients on their own stream + block-by-block tail" if two else "single-stream schedule"
+        free = timed()
+        line = f"  {name}: no thief {free:.2f}"
+        for n in (8, 32):
+            ms = timed(burst_cus=n)
+            line += f" | {n} CUs {ms:.2f} (+{ms - free:.2f} ms)"
+        hold = timed(hold_cus=16)
+        line += f" | 16 CUs for the whole step {hold:.2f}"
+        print(line, flush=True)
+schedule(False)

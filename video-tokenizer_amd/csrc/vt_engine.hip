@@ -88,6 +88,7 @@ struct vtTokenizer {
     size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
     const uint32_t* seed_ctr = nullptr;   // device-side per-call counter of the stochastic VQ (graph replay), see vt_vq_forward_ctr
     bool splitk_on = !g_no_splitk;           // vt_tokenizer_set_split_k / vt_stack_set_split_k; VT_GEMM_SPLITK=0 starts it off
+    int wg_tail = 0;                         // vt_tokenizer_set_wgrad_tail: the encoder's first wg_tail blocks (the LAST of the backward) flush their weight gradients block by block
     bool in_backward = false;                // set by the entry points: nt() hands the split-K workspace to backward GEMMs only
     size_t splitk = 0, splitk_bytes = 0;     // vt_gemm_nt's split-K partial sums + arrival counters (zeroed by *_init_workspace)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
@@ -101,7 +102,27 @@ struct vtTokenizer {
     LastBlock last_enc, last_dec;
     struct GradSet { size_t dx_out, dx_mid, du, dqkv, ln_part1, ln_part2, cs_part; };   // + the block's partial sums awaiting the grouped reduction
     static constexpr int WG_BATCH = 4;
-    GradSet gs[WG_BATCH + 1];
+    static constexpr int NSETS_MAX = 2 * WG_BATCH + 1;
+    GradSet gs[NSETS_MAX];    // WG_BATCH + 1 are in rotation; all of them when the weight gradients run on their own stream (below)
+    // Data-parallel runs: the deferred weight-gradient launches (and the partial-sum reductions of the same blocks) go to a SECOND stream
+    // (vt_tokenizer_set_wgrad_stream).  They are off the backward's critical path, and with a collective's workgroups resident the
+    // exact-fit GEMM launches of the main stream leave most of the chip idle in their extra round: work of an
+    // independent stream fills it.  Ordering: the side stream starts a group behind an event of the main stream (operands written);
+    // a gradient set is rewritten by the main stream only behind the event of the group that read it (twice the sets, so that wait is
+    // normally over); the last stage of backward joins the side stream.
+    hipStream_t wg_stream = nullptr;
+    static constexpr int NEV = 16;
+    hipEvent_t ev_fork[NEV] = {}, ev_done[NEV] = {};
+    int flush_id = 0;                 // groups flushed to the side stream so far (event slot = id % NEV)
+    int set_flush[NSETS_MAX];         // id of the side-stream group that last read the set, -1 = none pending
+    std::vector<int> sets_pending;    // sets used by the blocks whose weight gradients are queued
+    int nsets() const { return wg_stream ? NSETS_MAX : WG_BATCH + 1; }
+    ~vtTokenizer() {
+        for (int i = 0; i < NEV; ++i) {
+            if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
+            if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+        }
+    }
     // host-side state of an in-flight backward
     std::vector<vtGemmTN> pending;
     std::vector<vtReduceItem> pending_red;   // partial-sum reductions of the same blocks (one grouped launch at the flush)
@@ -224,6 +245,30 @@ extern "C" int vt_tokenizer_set_split_k(vtTokenizer* t, int32_t on) {
     return VT_OK;
 }
 extern "C" int vt_stack_set_split_k(vtStack* t, int32_t on) { return vt_tokenizer_set_split_k(t, on); }
+// Data-parallel runs: the gradients of a 4-block group only become final -- and their all-reduce can only start -- at the group's grouped
+// weight-gradient launch, so with the default schedule the encoder's blocks 3..0 (113 MB of fp32 gradients at config B) are reduced after
+// the last backward kernel, fully exposed.  With n > 0 the encoder's blocks below n are flushed block by block (n = 3: groups 3-2 | 1 | 0),
+// which leaves one block's 28 MB for the tail and costs three launches that do not fill whole rounds of the chip (+ ~0.17 ms of compute).
+// Same kernels on the same operands: gradients are bit-identical to the default schedule.
+extern "C" int vt_tokenizer_set_wgrad_stream(vtTokenizer* t, vtStream side) {
+    VT_CHECK_ARG(t, "vt_tokenizer_set_wgrad_stream: null handle");
+    VT_CHECK_ARG(t->pending.empty() && t->pending_red.empty(), "vt_tokenizer_set_wgrad_stream: a backward is in flight");
+    t->wg_stream = (hipStream_t)side;
+    for (int i = 0; i < vtTokenizer::NSETS_MAX; ++i) t->set_flush[i] = -1;
+    t->sets_pending.clear();
+    if (side) {
+        for (int i = 0; i < vtTokenizer::NEV; ++i) {
+            if (!t->ev_fork[i] && hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming) != hipSuccess) { vt_set_error("vt_tokenizer_set_wgrad_stream: event creation failed"); return VT_ERR_LAUNCH; }
+            if (!t->ev_done[i] && hipEventCreateWithFlags(&t->ev_done[i], hipEventDisableTiming) != hipSuccess) { vt_set_error("vt_tokenizer_set_wgrad_stream: event creation failed"); return VT_ERR_LAUNCH; }
+        }
+    }
+    return VT_OK;
+}
+extern "C" int vt_tokenizer_set_wgrad_tail(vtTokenizer* t, int32_t n) {
+    VT_CHECK_ARG(t && n >= 0, "vt_tokenizer_set_wgrad_tail: null handle or negative count");
+    t->wg_tail = n;
+    return VT_OK;
+}
 extern "C" int vt_tokenizer_set_seed_counter(vtTokenizer* t, const uint32_t* seed_counter) {
     VT_CHECK_ARG(t, "vt_tokenizer_set_seed_counter: null handle");
     t->seed_ctr = seed_counter;
@@ -313,6 +358,12 @@ static vtGemmNT nt(const vtTokenizer* t, void* ws, const void* A, int64_t lda, c
     // backward only: the forward pass of a clip stays bit-identical whatever batch it runs in (sampled token ids, reconstructions);
     // its gradients already differ across batch sizes in the last fp32 bits (summation over the batch's rows)
     if (t->splitk_bytes && t->in_backward && t->splitk_on) { p.splitk_ws = WS(void, t->splitk); p.splitk_ws_bytes = (int64_t)t->splitk_bytes; }
+    // data-parallel runs (wg_tail > 0 marks them): launches of several exact rounds of 192x192 tiles go out one tile per workgroup instead of
+    // as 256 persistent workgroups with fixed tile lists.  Equal speed on a free chip (62.9 vs 63.2 us on fc1 forward); with a collective's
+    // workgroups holding CUs the hardware dispatcher hands the remaining tiles to whichever CU is free (4 rounds -> 5), where a persistent
+    // workgroup that could not start runs its whole list after the others have finished theirs (x 1.67 measured, tools/cu_thief_stats.sh)
+    // (backward only: that is where the gradient all-reduce runs, and the forward's GELU launch would fill its look-up table once per tile)
+    if (t->wg_tail > 0 && t->in_backward && M % 192 == 0 && N % 192 == 0 && (long)(M / 192) * (N / 192) > 256) p.tile = 6;
     return p;
 }
 
@@ -483,7 +534,30 @@ static int skinny_wgrad(vtTokenizer* t, vtGemmTN w, void* ws, vtStream s) {
     return VT_ERR_INVALID;
 }
 
-static int flush_wgrads(vtTokenizer* t, int stage_done, vtStream s) {
+// the main stream is about to rewrite gradient set `set`: wait for the side-stream group that still reads it
+static int wait_set(vtTokenizer* t, int set, vtStream s) {
+    if (t->wg_stream && t->set_flush[set] >= 0) {
+        if (hipStreamWaitEvent((hipStream_t)s, t->ev_done[t->set_flush[set] % vtTokenizer::NEV], 0) != hipSuccess) { vt_set_error("wait_set: hipStreamWaitEvent failed"); return VT_ERR_LAUNCH; }
+        t->set_flush[set] = -1;
+    }
+    return VT_OK;
+}
+// all side-stream groups of this backward are done before the main stream goes on (end of backward)
+static int join_wgrad_stream(vtTokenizer* t, vtStream s) {
+    if (t->wg_stream && t->flush_id > 0) {
+        if (hipStreamWaitEvent((hipStream_t)s, t->ev_done[(t->flush_id - 1) % vtTokenizer::NEV], 0) != hipSuccess) { vt_set_error("join_wgrad_stream: hipStreamWaitEvent failed"); return VT_ERR_LAUNCH; }
+        for (int i = 0; i < vtTokenizer::NSETS_MAX; ++i) t->set_flush[i] = -1;   // the side stream runs its groups in order
+    }
+    return VT_OK;
+}
+
+static int flush_wgrads(vtTokenizer* t, int stage_done, vtStream main_s) {
+    vtStream s = main_s;
+    if (t->wg_stream) {
+        hipEvent_t fork = t->ev_fork[t->flush_id % vtTokenizer::NEV];
+        if (hipEventRecord(fork, (hipStream_t)main_s) != hipSuccess || hipStreamWaitEvent(t->wg_stream, fork, 0) != hipSuccess) { vt_set_error("flush_wgrads: fork failed"); return VT_ERR_LAUNCH; }
+        s = (vtStream)t->wg_stream;
+    }
     for (size_t i = 0; i < t->pending.size(); i += VT_TN_MAX_GROUP) {
         const int n = (int)((t->pending.size() - i) < VT_TN_MAX_GROUP ? (t->pending.size() - i) : VT_TN_MAX_GROUP);
         TRY(vt_gemm_tn_grouped(t->pending.data() + i, n, s));
@@ -496,6 +570,12 @@ static int flush_wgrads(vtTokenizer* t, int stage_done, vtStream s) {
     t->pending_red.clear();
     t->pending_blocks = 0;
     t->final_through = stage_done;
+    if (t->wg_stream) {
+        if (hipEventRecord(t->ev_done[t->flush_id % vtTokenizer::NEV], t->wg_stream) != hipSuccess) { vt_set_error("flush_wgrads: event record failed"); return VT_ERR_LAUNCH; }
+        for (int set : t->sets_pending) t->set_flush[set] = t->flush_id;
+        t->flush_id++;
+    }
+    t->sets_pending.clear();
     return VT_OK;
 }
 
@@ -521,8 +601,12 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     const vtTokenizerConfig& c = t->c;
     const int M = t->M, Mp = t->Mp, D = c.D, D3 = t->D3, D4 = t->D4;
     const vtRowMap id = {0, 0, 0};
+    const int set_next = (t->set_idx + 1) % t->nsets();
+    TRY(wait_set(t, t->set_idx, s));
+    TRY(wait_set(t, set_next, s));
+    t->sets_pending.push_back(t->set_idx);
     const vtTokenizer::GradSet& g0 = t->gs[t->set_idx];
-    const vtTokenizer::GradSet& g1 = t->gs[(t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1)];
+    const vtTokenizer::GradSet& g1 = t->gs[set_next];
     float* dX = WS(float, t->dX);
     void* dXa = WS(void, g0.dx_out);
     void* dXm = WS(void, g0.dx_mid);
@@ -560,7 +644,7 @@ static int block_backward(vtTokenizer* t, const BlockBufs& b, const vtBlockTenso
     TRY(vt_layernorm_bwd_partials(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
                                   WS(float, g0.ln_part1), &nsl, s));
     queue_ln_reduce(t, WS(float, g0.ln_part1), nsl, D, gr.norm1_w, gr.norm1_b, prev_bias_grad);
-    t->set_idx = (t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1);
+    t->set_idx = set_next;
     return VT_OK;
 }
 
@@ -572,8 +656,12 @@ static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb,
     const int M = t->M, Mp = t->Mp, D = c.D, D3 = t->D3, D4 = t->D4, Mk = lb.Mk, Mkp = lb.Mkp;
     const vtRowMap id = {0, 0, 0};
     const vtRowMap kmap = {lb.nk, t->L, lb.q_begin};
+    const int set_next = (t->set_idx + 1) % t->nsets();
+    TRY(wait_set(t, t->set_idx, s));
+    TRY(wait_set(t, set_next, s));
+    t->sets_pending.push_back(t->set_idx);
     const vtTokenizer::GradSet& g0 = t->gs[t->set_idx];
-    const vtTokenizer::GradSet& g1 = t->gs[(t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1)];
+    const vtTokenizer::GradSet& g1 = t->gs[set_next];
     float* dX = WS(float, t->dX);
     void* dXa = WS(void, lb.dxa);   // compact bf16 copies of dL/dx_out and dL/dx_mid, and du: rows >= Mk stay zero
     void* dXm = WS(void, lb.dxm);
@@ -605,7 +693,7 @@ static int block_backward_last(vtTokenizer* t, const vtTokenizer::LastBlock& lb,
     TRY(vt_layernorm_bwd_partials(WS(void, t->dh), x_in, id, w.norm1_w, WS(float, b.mean1), WS(float, b.rstd1), dX, M, D, dX, WS(void, g1.dx_out),
                                   WS(float, g0.ln_part1), &nsl, s));
     queue_ln_reduce(t, WS(float, g0.ln_part1), nsl, D, gr.norm1_w, gr.norm1_b, prev_bias_grad);
-    t->set_idx = (t->set_idx + 1) % (vtTokenizer::WG_BATCH + 1);
+    t->set_idx = set_next;
     return VT_OK;
 }
 
@@ -629,6 +717,8 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
         if (st == 0) {
             t->pending.clear();
             t->pending_red.clear(); t->pending_blocks = 0; t->set_idx = 0; t->final_through = 0;
+            t->sets_pending.clear();
+            TRY(join_wgrad_stream(t, s));    // (a previous backward that was not run to its last stage)
             // ---- head: d_pred -> patch rows (c,dt,dy,dx) -> dgrad / wgrad -> LayerNorm backward into the last Nv rows
             VT_CHECK_ARG(d_pred, "vt_tokenizer_backward: stage 0 needs d_pred");
             TRY(vt_patchify(d_pred, c.B, c.C, c.T, c.S, c.pt, c.p, WS(void, t->dY), s));
@@ -676,10 +766,12 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             w = tn(WS(void, t->dz_pad), 64, WS(void, t->zb), D, t->Mqp, 64, D, G->in_w, D);
             w.p_lim = c.d;
             TRY(skinny_wgrad(t, w, ws, s));
-            t->set_idx = 0;
-            TRY(vt_zero_rows(dX, WS(void, t->gs[0].dx_out), tmap, t->Mv, D, s));  // video-token rows get no gradient from the bottleneck
+            // (the encoder goes on in the rotation of gradient sets where the decoder stopped: with the weight gradients on their own
+            // stream, set 0 may still be read by the decoder's last group)
+            TRY(wait_set(t, t->set_idx, s));
+            TRY(vt_zero_rows(dX, WS(void, t->gs[t->set_idx].dx_out), tmap, t->Mv, D, s));  // video-token rows get no gradient from the bottleneck
             g = nt(t, ws, WS(void, t->dz_pad), 64, WS(void, t->in_wt), 64, t->Mq, D, 64, VT_EPI_F32, dX, D);
-            g.out2 = WS(void, t->gs[0].dx_out); g.ldo2 = D; g.omap = qmap;
+            g.out2 = WS(void, t->gs[t->set_idx].dx_out); g.ldo2 = D; g.omap = qmap;
             TRY(vt_gemm_nt(&g, s));
             TRY(vt_colsum(dX, 0, D, id, t->M, D, G->enc_blocks[c.depth_enc - 1].fc2_b, WS(void, t->cs_ws), s));
             t->final_through = st + 1;
@@ -690,7 +782,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
                 TRY(block_backward_last(t, t->last_enc, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
             else
                 TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
-            if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) TRY(flush_wgrads(t, st + 1, s));
+            if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0 || i < t->wg_tail) TRY(flush_wgrads(t, st + 1, s));
         } else {
             // ---- patch embed + learned queries.  dX holds dL/d(encoder input sequence)
             TRY(vt_batch_sum(dX, qmap, c.B, Nq, D, G->enc_query, s));
@@ -698,6 +790,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
             TRY(vt_colsum(WS(void, t->dTok), 1, D, id, t->Mv, D, G->pe_b, WS(void, t->cs_ws), s));
             vtGemmTN w = tn(WS(void, t->dTok), D, WS(void, t->patches), Kp, t->Mvp, D, Kp, G->pe_w, Kp);
             TRY(vt_gemm_tn_grouped(&w, 1, s));
+            TRY(join_wgrad_stream(t, s));    // every gradient of the step is behind the caller's stream from here on
             t->final_through = st + 1;
         }
     }

@@ -128,6 +128,8 @@ class TokenizerEngine:
         self.reducer = None   # set by parallel.DataParallelTokenizer
         self.seed_counter = 0
         self.split_k = None   # None = the library's default (on unless VT_GEMM_SPLITK=0); set_split_k() overrides it for every geometry
+        self.wgrad_tail = 0   # set_wgrad_tail(): flush the encoder's first blocks' weight gradients block by block (data-parallel runs)
+        self.wgrad_stream = None   # set_wgrad_stream(): torch.cuda.Stream the deferred weight-gradient launches run on (data-parallel runs)
         self.graph_mode = False   # GraphedStep: weights are re-packed inside the captured step, the VQ seed counter lives on the device
 
     def __deepcopy__(self, memo):
@@ -207,8 +209,31 @@ class TokenizerEngine:
             st = _State(self, key, c, device)
             if self.split_k is not None:
                 hip.check(hip.lib().vt_tokenizer_set_split_k(st.handle, int(self.split_k)), "vt_tokenizer_set_split_k")
+            if self.wgrad_tail:
+                hip.check(hip.lib().vt_tokenizer_set_wgrad_tail(st.handle, int(self.wgrad_tail)), "vt_tokenizer_set_wgrad_tail")
+            if self.wgrad_stream is not None:
+                hip.check(hip.lib().vt_tokenizer_set_wgrad_stream(st.handle, self.wgrad_stream.cuda_stream), "vt_tokenizer_set_wgrad_stream")
             self.states[key] = st
         return st
+
+    def set_wgrad_stream(self, stream):
+        """Data-parallel runs (vt_tokenizer_set_wgrad_stream): the deferred weight-gradient launches and the partial-sum reductions of the same
+        blocks run on `stream` (a torch.cuda.Stream, or None for the single-stream schedule) next to the backward's critical path; the engine
+        orders both streams with events and joins them at the last stage of backward.  Bit-identical gradients.  Whoever consumes a finished
+        gradient slice before the end of backward (parallel.GradReducer) has to wait for this stream as well.  Not for GraphedStep."""
+        if stream is not None and any(st.graphed for st in self.states.values()):
+            raise RuntimeError("set_wgrad_stream: a geometry of this engine is captured in a hipGraph (GraphedStep); the two-stream schedule is not capturable")
+        self.wgrad_stream = stream
+        for st in self.states.values():
+            hip.check(hip.lib().vt_tokenizer_set_wgrad_stream(st.handle, stream.cuda_stream if stream is not None else None), "vt_tokenizer_set_wgrad_stream")
+
+    def set_wgrad_tail(self, n):
+        """Data-parallel runs (vt_tokenizer_set_wgrad_tail): the encoder's blocks below n flush their weight gradients block by block, so
+        the gradient slice that becomes final at the very end of backward -- whose all-reduce nothing can hide -- is one block's instead of
+        four blocks'.  Same kernels on the same operands: bit-identical gradients; ~0.17 ms more compute per step at config B."""
+        self.wgrad_tail = max(0, int(n))
+        for st in self.states.values():
+            hip.check(hip.lib().vt_tokenizer_set_wgrad_tail(st.handle, self.wgrad_tail), "vt_tokenizer_set_wgrad_tail")
 
     def set_split_k(self, on):
         """Split K in the backward input-gradient GEMMs at one / two clips per GPU (vt_tokenizer_set_split_k): +8 % there, at the price of
@@ -384,6 +409,8 @@ class GraphedStep:
             raise NotImplementedError("GraphedStep needs the fused engine (this model runs on the composed path)")
         if eng.reducer is not None:
             raise NotImplementedError("GraphedStep: the data-parallel gradient reducer is not captured; use the eager step under DataParallelTokenizer")
+        if eng.wgrad_stream is not None:
+            raise NotImplementedError("GraphedStep: the two-stream weight-gradient schedule (set_wgrad_stream) is not capturable; call set_wgrad_stream(None) first")
         self.model, self.engine, self.loss_fn = model, eng, loss_fn
         from .optim import flatten_parameters
         flatten_parameters(model)       # parameter ADDRESSES are baked into the graph: move them into the flat buffer FusedAdam uses now, not later

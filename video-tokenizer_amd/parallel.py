@@ -11,6 +11,8 @@ every RCCL call is bandwidth- not latency-bound, and there are only ~11 of them 
 Semantics preserved from DDP: gradient MEAN over ranks; parameters broadcast from rank 0 at wrap time.
 The same code runs on CPU tensors with the gloo backend (tests), synchronously.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -29,6 +31,8 @@ class GradReducer:
         self.use_avg = dist.get_backend(process_group) == "nccl"
         # inspection (tests / tools): with record_events set, every bucket's collective is bracketed by timing events on the
         # comm stream and finish() records one on the compute stream behind the last backward kernel -> `events`
+        # a second stream that also writes gradients (engine.set_wgrad_stream): a slice is ready when BOTH streams have passed this point
+        self.extra_stream = None
         self.record_events = False
         self.events = []      # [(start, stop)] per launched bucket of the last backward
         self.compute_done = None
@@ -43,6 +47,10 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(flat.device))  # slice fully written by kernels enqueued so far
             self.comm_stream.wait_event(ev)
+            if self.extra_stream is not None:
+                ev2 = torch.cuda.Event()
+                ev2.record(self.extra_stream)
+                self.comm_stream.wait_event(ev2)
             with torch.cuda.stream(self.comm_stream):
                 if self.record_events:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -113,6 +121,19 @@ class DataParallelTokenizer(nn.Module):
                     if t.data_ptr() not in inside:
                         dist.broadcast(t, src=0, group=process_group)
         module._engine.reducer = GradReducer(process_group, bucket_bytes)
+        # the slice that becomes final with the LAST weight-gradient launch is reduced with no backward left to hide it: flush the encoder's
+        # first three blocks one group at a time (3-2 | 1 | 0) so that slice is one block's 28 MB instead of four blocks' 113 MB
+        # (vt_tokenizer_set_wgrad_tail; VT_WGRAD_TAIL=0 keeps the single-GPU schedule)
+        module._engine.set_wgrad_tail(int(os.environ.get("VT_WGRAD_TAIL", "3")))
+        # OPT-IN (VT_WGRAD_STREAM=1): the deferred weight-gradient launches on a stream of their own (vt_tokenizer_set_wgrad_stream).  While
+        # a collective's workgroups hold CUs every exact-fit GEMM launch of the backward runs an extra, nearly empty round (+ 33 % on the
+        # step, tools/cu_thief_probe.py); independent weight-gradient work can fill those rounds.  Measured with the stand-in on one GPU
+        # (profiles/r04_cu_thief_probe.log): it costs 0.3 ms per step when nothing is resident, breaks even at ~3.5 ms of residency per
+        # step and wins 1.1 ms when a collective is resident throughout -- so it is off until a multi-GPU box says which regime RCCL is in.
+        if os.environ.get("VT_WGRAD_STREAM", "0") == "1" and next(module.parameters()).is_cuda:
+            side = torch.cuda.Stream(device=next(module.parameters()).device)
+            module._engine.set_wgrad_stream(side)
+            module._engine.reducer.extra_stream = side
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
