@@ -255,11 +255,7 @@ extern "C" int vt_tokenizer_set_split_k(vtTokenizer* t, int32_t on) {
     return VT_OK;
 }
 extern "C" int vt_stack_set_split_k(vtStack* t, int32_t on) { return vt_tokenizer_set_split_k(t, on); }
-// Data-parallel runs: the gradients of a 4-block group only become final -- and their all-reduce can only start -- at the group's grouped
-// weight-gradient launch, so with the default schedule the encoder's blocks 3..0 (113 MB of fp32 gradients at config B) are reduced after
-// the last backward kernel, fully exposed.  With n > 0 the encoder's blocks below n are flushed block by block (n = 3: groups 3-2 | 1 | 0),
-// which leaves one block's 28 MB for the tail and costs three launches that do not fill whole rounds of the chip (+ ~0.17 ms of compute).
-// Same kernels on the same operands: gradients are bit-identical to the default schedule.
+// Data-parallel runs: the weight-gradient launches on a stream of their own (see the members above); NULL = single-stream schedule.
 extern "C" int vt_tokenizer_set_wgrad_stream(vtTokenizer* t, vtStream side) {
     VT_CHECK_ARG(t, "vt_tokenizer_set_wgrad_stream: null handle");
     VT_CHECK_ARG(t->pending.empty() && t->pending_red.empty(), "vt_tokenizer_set_wgrad_stream: a backward is in flight");
@@ -274,6 +270,12 @@ extern "C" int vt_tokenizer_set_wgrad_stream(vtTokenizer* t, vtStream side) {
     }
     return VT_OK;
 }
+// Data-parallel runs: the gradients of a 4-block group only become final -- and their all-reduce can only start -- at the group's grouped
+// weight-gradient launch, so with the default schedule the encoder's blocks 3..0 (113 MB of fp32 gradients at config B) are reduced after
+// the last backward kernel, fully exposed.  With n > 0 the encoder's blocks below n are flushed block by block (n = 3: groups 3-2 | 1 | 0),
+// which leaves one block's 28 MB for the tail and costs three launches that do not fill whole rounds of the chip (+ ~0.1 ms of compute).
+// Same kernels on the same operands: gradients are bit-identical to the default schedule.
+// n > 0 also marks the handle as data-parallel for nt(): the backward's multi-round GEMMs then go out one tile per workgroup.
 extern "C" int vt_tokenizer_set_wgrad_tail(vtTokenizer* t, int32_t n) {
     VT_CHECK_ARG(t && n >= 0, "vt_tokenizer_set_wgrad_tail: null handle or negative count");
     t->wg_tail = n;
