@@ -11,7 +11,7 @@ spinning on the real-time counter).  This script runs bench.py's step next to it
     tail: engine.set_wgrad_stream / set_wgrad_tail, what parallel.DataParallelTokenizer switches on).
 
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/cu_thief.hip -o tools/probes/_bin/libcu_thief.so   # in the dev container
-    python3 tools/cu_thief_probe.py [clips] [burst_ms]"""
+    python3 tools/cu_thief_probe.py [clips] [burst_ms,burst_ms,...]"""
 import ctypes
 import os
 import sys
@@ -25,7 +25,7 @@ import video_tokenizer_amd as vt  # noqa: E402
 from video_tokenizer_amd.config import geometry, model_spec  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-BURST = float(sys.argv[2]) if len(sys.argv) > 2 else 3.5
+BURST = 3.5
 thief = ctypes.CDLL(os.path.join(R, "tools", "probes", "_bin", "libcu_thief.so"))
 thief.thief_launch.restype = ctypes.c_int
 thief.thief_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
@@ -74,28 +74,32 @@ def timed(hold_cus=0, burst_cus=0, steps=10):
     return ms
 
 
-def schedule(two_streams):
-    eng.set_wgrad_stream(wg_stream if two_streams else None)
-    eng.set_wgrad_tail(3 if two_streams else 0)
+def schedule(kind):
+    """0: the single-GPU schedule; 1: DataParallelTokenizer's default (block-by-block tail, the backward's multi-round GEMMs one tile per
+    workgroup); 2: 1 + the weight gradients on their own stream (VT_WGRAD_STREAM=1)"""
+    eng.set_wgrad_stream(wg_stream if kind == 2 else None)
+    eng.set_wgrad_tail(3 if kind else 0)
 
 
-schedule(False)
+NAMES = ("single-GPU schedule", "data-parallel default (tail 3-2|1|0, one tile per workgroup)", "data-parallel + weight gradients on their own stream")
+schedule(0)
 base = timed()
-print(f"{B} clips per GPU, forward + backward, ms per step (10 steps, events).  single-stream schedule, no thief: {base:.2f}", flush=True)
+print(f"{B} clips per GPU, forward + backward, ms per step (10 steps, events).  single-GPU schedule, no thief: {base:.2f}", flush=True)
 for n in (4, 16, 64):
     ms = timed(hold_cus=n)
     print(f"  {n:3d} CUs held for the whole step: {ms:.2f} ms (+{100 * (ms / base - 1):.1f} %; CUs lost {100 * n / 256:.1f} %)", flush=True)
-print(f"bursts: a thief of {BURST} ms behind the forward of every step (a collective resident that long inside the backward)", flush=True)
+bursts = [float(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3.5]
+print("bursts: a thief of 16 CUs behind the forward of every step for b ms (a collective resident that long inside the backward)", flush=True)
 for rnd in range(2):
-    for two in (False, True):
-        schedule(two)
-        name = "weight gradients on their own stream + block-by-block tail" if two else "single-stream schedule"
+    for kind in (0, 1, 2):
+        schedule(kind)
         free = timed()
-        line = f"  {name}: no thief {free:.2f}"
-        for n in (8, 32):
-            ms = timed(burst_cus=n)
-            line += f" | {n} CUs {ms:.2f} (+{ms - free:.2f} ms)"
+        line = f"  {NAMES[kind]}: no thief {free:.2f}"
+        for b in bursts:
+            BURST = b
+            ms = timed(burst_cus=16)
+            line += f" | {b} ms: {ms:.2f}"
         hold = timed(hold_cus=16)
-        line += f" | 16 CUs for the whole step {hold:.2f}"
+        line += f" | whole step: {hold:.2f}"
         print(line, flush=True)
-schedule(False)
+schedule(0)

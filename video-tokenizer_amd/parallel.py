@@ -125,12 +125,13 @@ class DataParallelTokenizer(nn.Module):
         # first three blocks one group at a time (3-2 | 1 | 0) so that slice is one block's 28 MB instead of four blocks' 113 MB
         # (vt_tokenizer_set_wgrad_tail; VT_WGRAD_TAIL=0 keeps the single-GPU schedule)
         module._engine.set_wgrad_tail(int(os.environ.get("VT_WGRAD_TAIL", "3")))
-        # OPT-IN (VT_WGRAD_STREAM=1): the deferred weight-gradient launches on a stream of their own (vt_tokenizer_set_wgrad_stream).  While
-        # a collective's workgroups hold CUs every exact-fit GEMM launch of the backward runs an extra, nearly empty round (+ 33 % on the
-        # step, tools/cu_thief_probe.py); independent weight-gradient work can fill those rounds.  Measured with the stand-in on one GPU
-        # (profiles/r04_cu_thief_probe.log): it costs 0.3 ms per step when nothing is resident, breaks even at ~3.5 ms of residency per
-        # step and wins 1.1 ms when a collective is resident throughout -- so it is off until a multi-GPU box says which regime RCCL is in.
-        if os.environ.get("VT_WGRAD_STREAM", "0") == "1" and next(module.parameters()).is_cuda:
+        # the deferred weight-gradient launches on a stream of their own (vt_tokenizer_set_wgrad_stream; VT_WGRAD_STREAM=0 = single stream).
+        # While a collective's workgroups hold CUs, every exact-fit GEMM launch of the backward runs an extra, nearly empty round
+        # (tools/cu_thief_probe.py: + 33 % on the step while something is resident); independent weight-gradient work fills part of those
+        # rounds.  With the stand-in resident for 2.7 / 5.4 / 12.6 ms of the backward (what an all-reduce of the step's 694 MB keeps
+        # resident at 8 / 4 / 2 GPUs) the step takes 24.7 / 25.0 / 25.8 ms against 24.8 / 25.2 / 26.4 ms on one stream
+        # (profiles/r04_cu_thief_probe.log); it costs 0.1 ms when nothing is resident, which a data-parallel run never sees.
+        if os.environ.get("VT_WGRAD_STREAM", "1") != "0" and next(module.parameters()).is_cuda:
             side = torch.cuda.Stream(device=next(module.parameters()).device)
             module._engine.set_wgrad_stream(side)
             module._engine.reducer.extra_stream = side
