@@ -6,9 +6,9 @@ GEMMs of the step see 256 - n CUs.  tools/probes/cu_thief.hip holds n CUs the sa
 spinning on the real-time counter).  This script runs bench.py's step next to it
 
   * for the WHOLE step (the upper bound), n = 4 ... 64, single-stream schedule;
-  * and in BURSTS: a thief of `burst_ms` started behind the forward of every step -- a collective resident for that long inside the
-    backward -- under the single-stream schedule and under the data-parallel one (weight gradients on their own stream, block-by-block
-    tail: engine.set_wgrad_stream / set_wgrad_tail, what parallel.DataParallelTokenizer switches on).
+  * and in BURSTS: a thief of `burst_ms` started when the first gradient slice of every backward is final -- where the first bucket's
+    collective would start -- under the single-GPU schedule, under DataParallelTokenizer's (block-by-block tail, multi-round GEMMs one
+    tile per workgroup, weight gradients on their own stream: engine.set_wgrad_tail / set_wgrad_stream) and under that without the stream.
 
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/cu_thief.hip -o tools/probes/_bin/libcu_thief.so   # in the dev container
     python3 tools/cu_thief_probe.py [clips] [burst_ms,burst_ms,...]"""
@@ -40,7 +40,30 @@ eng = model._engine
 x = torch.from_numpy(vt.config.synthetic_clips(B, c["frame_num"], c["input_size"], 100)).cuda()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 thief_stream = torch.cuda.Stream()
-wg_stream = torch.cuda.Stream()
+wg_stream = torch.cuda.Stream(priority=int(os.environ.get("VT_THIEF_WG_PRIORITY", "0")))
+
+
+class ThiefAtFirstBucket:
+    """Stands where parallel.GradReducer stands (engine.reducer): the backward then runs stage by stage, and when the FIRST gradient
+    slice is reported final -- the moment the first bucket's collective would be launched -- the thief starts, behind the kernels
+    enqueued so far on both streams."""
+
+    def __init__(self):
+        self.cus, self.fired = 0, False
+
+    def segment_ready(self, flat, lo, hi):
+        if self.cus and not self.fired:
+            thief_stream.wait_stream(torch.cuda.current_stream())
+            if eng.wgrad_stream is not None:
+                thief_stream.wait_stream(eng.wgrad_stream)
+            assert thief.thief_launch(self.cus, BURST, sink.data_ptr(), thief_stream.cuda_stream) == 0
+            self.fired = True
+
+    def finish(self):
+        self.fired = False
+
+
+at_bucket = ThiefAtFirstBucket()
 
 
 def step(burst_cus=0):
@@ -48,9 +71,7 @@ def step(burst_cus=0):
     loss = (out["pred_frames"] - x).abs().mean() + 0.1 * out["loss_q"]
     for p in model.parameters():
         p.grad = None
-    if burst_cus:
-        thief_stream.wait_stream(torch.cuda.current_stream())       # the thief arrives when the forward is done, like the first bucket's collective
-        assert thief.thief_launch(burst_cus, BURST, sink.data_ptr(), thief_stream.cuda_stream) == 0
+    at_bucket.cus = burst_cus
     loss.backward()
 
 
@@ -82,6 +103,7 @@ def schedule(kind):
 
 
 NAMES = ("single-GPU schedule", "data-parallel default (tail 3-2|1|0, one tile per workgroup)", "data-parallel + weight gradients on their own stream")
+eng.reducer = at_bucket            # every backward of this script runs stage by stage, as under DataParallelTokenizer
 schedule(0)
 base = timed()
 print(f"{B} clips per GPU, forward + backward, ms per step (10 steps, events).  single-GPU schedule, no thief: {base:.2f}", flush=True)
@@ -89,7 +111,7 @@ for n in (4, 16, 64):
     ms = timed(hold_cus=n)
     print(f"  {n:3d} CUs held for the whole step: {ms:.2f} ms (+{100 * (ms / base - 1):.1f} %; CUs lost {100 * n / 256:.1f} %)", flush=True)
 bursts = [float(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3.5]
-print("bursts: a thief of 16 CUs behind the forward of every step for b ms (a collective resident that long inside the backward)", flush=True)
+print("bursts: a thief of 16 CUs for b ms, started when the first gradient slice of every backward is final (where the first bucket's collective starts)", flush=True)
 for rnd in range(2):
     for kind in (0, 1, 2):
         schedule(kind)
