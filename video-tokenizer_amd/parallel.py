@@ -129,7 +129,7 @@ class DataParallelTokenizer(nn.Module):
         # While a collective's workgroups hold CUs, every exact-fit GEMM launch of the backward runs an extra, nearly empty round
         # (tools/cu_thief_probe.py: + 33 % on the step while something is resident); independent weight-gradient work fills part of those
         # rounds.  With the stand-in resident for 2.7 / 5.4 / 12.6 ms of the backward (what an all-reduce of the step's 694 MB keeps
-        # resident at 8 / 4 / 2 GPUs) the step takes 24.7 / 25.0 / 25.8 ms against 24.8 / 25.2 / 26.4 ms on one stream
+        # resident at 8 / 4 / 2 GPUs) the step takes 24.8 / 25.1 / 26.0 ms against 24.9 / 25.4 / 26.5 ms on one stream
         # (profiles/r04_cu_thief_probe.log); it costs 0.1 ms when nothing is resident, which a data-parallel run never sees.
         if os.environ.get("VT_WGRAD_STREAM", "1") != "0" and next(module.parameters()).is_cuda:
             side = torch.cuda.Stream(device=next(module.parameters()).device)
