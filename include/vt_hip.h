@@ -452,6 +452,8 @@ int vt_tokenizer_set_wgrad_tail(vtTokenizer* tk, int32_t n);
  * an independent stream fills it.  A consumer of a finished gradient slice (final_through of vt_tokenizer_backward) must wait for BOTH
  * streams.  Same kernels on the same operands: bit-identical gradients.  NULL restores the single-stream schedule.  Not capturable. */
 int vt_tokenizer_set_wgrad_stream(vtTokenizer* tk, vtStream side);
+/* Blocks per grouped weight-gradient launch, 1..4 (default 4 = 768 tiles = three whole rounds of the chip at config B).  (ABI 7) */
+int vt_tokenizer_set_wgrad_batch(vtTokenizer* tk, int32_t n);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);

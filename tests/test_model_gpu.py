@@ -234,6 +234,12 @@ def test_weight_gradient_tail_schedule_is_bit_identical():
         assert got.keys() == base.keys()
         bad = [k for k in base if not torch.equal(got[k], base[k])]
         assert not bad, (n, bad[:5])
+    for batch in (1, 2, 3):                        # vt_tokenizer_set_wgrad_batch: blocks per grouped weight-gradient launch
+        model._engine.set_wgrad_batch(batch)
+        got = grads(3)
+        bad = [k for k in base if not torch.equal(got[k], base[k])]
+        assert not bad, (batch, bad[:5])
+    model._engine.set_wgrad_batch(4)
     model._engine.set_wgrad_tail(0)
 
 

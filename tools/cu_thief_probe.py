@@ -98,11 +98,14 @@ def timed(hold_cus=0, burst_cus=0, steps=10):
 def schedule(kind):
     """0: the single-GPU schedule; 1: DataParallelTokenizer's default (block-by-block tail, the backward's multi-round GEMMs one tile per
     workgroup); 2: 1 + the weight gradients on their own stream (VT_WGRAD_STREAM=1)"""
-    eng.set_wgrad_stream(wg_stream if kind == 2 else None)
+    eng.set_wgrad_stream(wg_stream if kind >= 2 else None)
     eng.set_wgrad_tail(3 if kind else 0)
+    eng.set_wgrad_batch({3: 2, 4: 1}.get(kind, 4))
 
 
-NAMES = ("single-GPU schedule", "data-parallel default (tail 3-2|1|0, one tile per workgroup)", "data-parallel + weight gradients on their own stream")
+NAMES = ("single-GPU schedule", "data-parallel default (tail 3-2|1|0, one tile per workgroup)", "data-parallel + weight gradients on their own stream",
+         "... + groups of 2 blocks", "... + groups of 1 block")
+KINDS = tuple(int(v) for v in os.environ.get("VT_THIEF_KINDS", "0,1,2").split(","))
 eng.reducer = at_bucket            # every backward of this script runs stage by stage, as under DataParallelTokenizer
 schedule(0)
 base = timed()
@@ -113,7 +116,7 @@ for n in (4, 16, 64):
 bursts = [float(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3.5]
 print("bursts: a thief of 16 CUs for b ms, started when the first gradient slice of every backward is final (where the first bucket's collective starts)", flush=True)
 for rnd in range(2):
-    for kind in (0, 1, 2):
+    for kind in KINDS:
         schedule(kind)
         free = timed()
         line = f"  {NAMES[kind]}: no thief {free:.2f}"

@@ -98,6 +98,7 @@ struct vtTokenizer {
     size_t dX, dh, dob, delta, ln_ws, cs_ws, cs_part, dY, dhN, dEncb, d_rz, dz_pad, dTok, tmp_vec, wg_slabs;
     const uint32_t* seed_ctr = nullptr;   // device-side per-call counter of the stochastic VQ (graph replay), see vt_vq_forward_ctr
     bool splitk_on = !g_no_splitk;           // vt_tokenizer_set_split_k / vt_stack_set_split_k; VT_GEMM_SPLITK=0 starts it off
+    int wg_batch = 4;                        // vt_tokenizer_set_wgrad_batch: blocks per grouped weight-gradient launch (1..WG_BATCH)
     int wg_tail = 0;                         // vt_tokenizer_set_wgrad_tail: the encoder's first wg_tail blocks (the LAST of the backward) flush their weight gradients block by block
     bool in_backward = false;                // set by the entry points: nt() hands the split-K workspace to backward GEMMs only
     size_t splitk = 0, splitk_bytes = 0;     // vt_gemm_nt's split-K partial sums + arrival counters (zeroed by *_init_workspace)
@@ -279,6 +280,14 @@ extern "C" int vt_tokenizer_set_wgrad_stream(vtTokenizer* t, vtStream side) {
 extern "C" int vt_tokenizer_set_wgrad_tail(vtTokenizer* t, int32_t n) {
     VT_CHECK_ARG(t && n >= 0, "vt_tokenizer_set_wgrad_tail: null handle or negative count");
     t->wg_tail = n;
+    return VT_OK;
+}
+// blocks per grouped weight-gradient launch, 1..4 (default 4: 768 tiles = three whole rounds of the chip).  Smaller groups hand the gradient
+// reducer finished slices sooner and, with the weight gradients on their own stream, keep that stream supplied with work throughout the backward.
+extern "C" int vt_tokenizer_set_wgrad_batch(vtTokenizer* t, int32_t n) {
+    VT_CHECK_ARG(t && n >= 1 && n <= vtTokenizer::WG_BATCH, "vt_tokenizer_set_wgrad_batch: null handle or n outside 1..%d", vtTokenizer::WG_BATCH);
+    VT_CHECK_ARG(t->pending.empty(), "vt_tokenizer_set_wgrad_batch: a backward is in flight");
+    t->wg_batch = n;
     return VT_OK;
 }
 extern "C" int vt_tokenizer_set_seed_counter(vtTokenizer* t, const uint32_t* seed_counter) {
@@ -756,7 +765,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
                 TRY(block_backward_last(t, t->last_dec, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), prev, ws, s));
             else
                 TRY(block_backward(t, t->dec[i], P->dec_blocks[i], G->dec_blocks[i], WS(float, t->x_dec[i]), prev, ws, s));
-            if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) TRY(flush_wgrads(t, st + 1, s));
+            if (t->pending_blocks >= t->wg_batch || i == 0) TRY(flush_wgrads(t, st + 1, s));
         } else if (st == c.depth_dec + 1) {
             // ---- bottleneck.  dX holds dL/d(decoder input sequence)
             if (G->dec_token_type) TRY(vt_colsum(dX, 0, D, vmap, t->Mv, D, G->dec_token_type, WS(void, t->cs_ws), s));
@@ -794,7 +803,7 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
                 TRY(block_backward_last(t, t->last_enc, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
             else
                 TRY(block_backward(t, t->enc[i], P->enc_blocks[i], G->enc_blocks[i], WS(float, t->x_enc[i]), prev, ws, s));
-            if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0 || i < t->wg_tail) TRY(flush_wgrads(t, st + 1, s));
+            if (t->pending_blocks >= t->wg_batch || i == 0 || i < t->wg_tail) TRY(flush_wgrads(t, st + 1, s));
         } else {
             // ---- patch embed + learned queries.  dX holds dL/d(encoder input sequence)
             TRY(vt_batch_sum(dX, qmap, c.B, Nq, D, G->enc_query, s));
@@ -901,7 +910,7 @@ extern "C" int vt_stack_backward(vtStack* t, const vtBlockTensors* blocks, const
             t->pending.clear();      // (the parameter gradients of a frozen stack are not wanted either: drop the queued reductions)
             t->pending_red.clear();
             t->pending_blocks = 0;
-        } else if (t->pending_blocks == vtTokenizer::WG_BATCH || i == 0) {
+        } else if (t->pending_blocks >= t->wg_batch || i == 0) {
             TRY(flush_wgrads(t, 0, s));
         }
     }

@@ -129,6 +129,7 @@ class TokenizerEngine:
         self.seed_counter = 0
         self.split_k = None   # None = the library's default (on unless VT_GEMM_SPLITK=0); set_split_k() overrides it for every geometry
         self.wgrad_tail = 0   # set_wgrad_tail(): flush the encoder's first blocks' weight gradients block by block (data-parallel runs)
+        self.wgrad_batch = 0    # set_wgrad_batch(): blocks per grouped weight-gradient launch (0 = the library's 4)
         self.wgrad_stream = None   # set_wgrad_stream(): torch.cuda.Stream the deferred weight-gradient launches run on (data-parallel runs)
         self.graph_mode = False   # GraphedStep: weights are re-packed inside the captured step, the VQ seed counter lives on the device
 
@@ -213,8 +214,16 @@ class TokenizerEngine:
                 hip.check(hip.lib().vt_tokenizer_set_wgrad_tail(st.handle, int(self.wgrad_tail)), "vt_tokenizer_set_wgrad_tail")
             if self.wgrad_stream is not None:
                 hip.check(hip.lib().vt_tokenizer_set_wgrad_stream(st.handle, self.wgrad_stream.cuda_stream), "vt_tokenizer_set_wgrad_stream")
+            if self.wgrad_batch:
+                hip.check(hip.lib().vt_tokenizer_set_wgrad_batch(st.handle, self.wgrad_batch), "vt_tokenizer_set_wgrad_batch")
             self.states[key] = st
         return st
+
+    def set_wgrad_batch(self, n):
+        """Blocks per grouped weight-gradient launch, 1..4 (vt_tokenizer_set_wgrad_batch; the library's default is 4).  Bit-identical gradients."""
+        self.wgrad_batch = int(n)
+        for st in self.states.values():
+            hip.check(hip.lib().vt_tokenizer_set_wgrad_batch(st.handle, self.wgrad_batch), "vt_tokenizer_set_wgrad_batch")
 
     def set_wgrad_stream(self, stream):
         """Data-parallel runs (vt_tokenizer_set_wgrad_stream): the deferred weight-gradient launches and the partial-sum reductions of the same

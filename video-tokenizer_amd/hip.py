@@ -175,6 +175,7 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_set_split_k": (c_i32, [c_vp, c_i32]),
     "vt_tokenizer_set_wgrad_tail": (c_i32, [c_vp, c_i32]),
     "vt_tokenizer_set_wgrad_stream": (c_i32, [c_vp, c_vp]),
+    "vt_tokenizer_set_wgrad_batch": (c_i32, [c_vp, c_i32]),
     "vt_stack_set_split_k": (c_i32, [c_vp, c_i32]),
     "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, ctypes.POINTER(c_i32), c_vp]),
 }

@@ -125,6 +125,8 @@ class DataParallelTokenizer(nn.Module):
         # first three blocks one group at a time (3-2 | 1 | 0) so that slice is one block's 28 MB instead of four blocks' 113 MB
         # (vt_tokenizer_set_wgrad_tail; VT_WGRAD_TAIL=0 keeps the single-GPU schedule)
         module._engine.set_wgrad_tail(int(os.environ.get("VT_WGRAD_TAIL", "3")))
+        if os.environ.get("VT_WGRAD_BATCH"):   # blocks per grouped weight-gradient launch (1..4, default 4): smaller groups report finished
+            module._engine.set_wgrad_batch(int(os.environ["VT_WGRAD_BATCH"]))   # slices sooner; measured neutral on compute with the second stream
         # the deferred weight-gradient launches on a stream of their own (vt_tokenizer_set_wgrad_stream; VT_WGRAD_STREAM=0 = single stream).
         # While a collective's workgroups hold CUs, every exact-fit GEMM launch of the backward runs an extra, nearly empty round
         # (tools/cu_thief_probe.py: + 33 % on the step while something is resident); independent weight-gradient work fills part of those
