@@ -24,8 +24,11 @@ model = vt.make(model_spec(c, stochastic=True))
 with torch.no_grad():
     torch.nn.init.xavier_uniform_(model.final_layer.linear.weight)
 model = model.cuda().train()
-if os.environ.get("VT_THIEF_DP") == "1":       # the schedule parallel.DataParallelTokenizer switches on (block-by-block tail, one tile per workgroup for multi-round GEMMs)
-    model._engine.set_wgrad_tail(3)
+if os.environ.get("VT_THIEF_DP") in ("1", "2"):   # the schedule parallel.DataParallelTokenizer switches on: block-by-block tail + one tile per workgroup for the
+    model._engine.set_wgrad_tail(3)               # backward's multi-round GEMMs (1), and the weight gradients on their own stream as well (2)
+    if os.environ["VT_THIEF_DP"] == "2":
+        wg_stream = torch.cuda.Stream()
+        model._engine.set_wgrad_stream(wg_stream)
 x = torch.from_numpy(vt.config.synthetic_clips(8, c["frame_num"], c["input_size"], 100)).cuda()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 side = torch.cuda.Stream()
