@@ -157,8 +157,8 @@ def test_data_parallel_wrapper_single_rank_rccl():
         wrapped = run(dp)
         assert red.launched and red.launched[0][0] == 0 and red.launched[-1][1] == sum(p.numel() for p in model.parameters())
         assert all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:])) and len(red.launched) >= 3
-        for n in plain:
-            assert torch.equal(plain[n], wrapped[n]), n
+        bad = {n: float((plain[n] - wrapped[n]).abs().max()) for n in plain if not torch.equal(plain[n], wrapped[n])}
+        assert not bad, (len(bad), list(bad.items())[:12])
         model._engine.reducer = None
     finally:
         if created:

@@ -363,8 +363,6 @@ class TokenizerFunction(torch.autograd.Function):
         done = 0
         # without a reducer the whole backward is one enqueue; with one, stage by stage so finished slices can be reduced
         chunks = [(s_, s_ + 1) for s_ in range(st.nstages)] if red is not None else [(0, st.nstages)]
-        if red is not None and getattr(red, "total", 0) is None:
-            red.total = max(hi for _, hi in engine.segments.values())    # the reducer lets the last slices go as they finish
         for lo_s, hi_s in chunks:
             hip.check(lib.vt_tokenizer_backward(st.handle, ctypes.byref(ps.struct), hip.ptr(d_pred), hip.ptr(gscal), hip.ptr(st.ws),
                                                 ctypes.byref(engine.grad_struct.struct), lo_s, hi_s, ctypes.byref(final), hip.stream()),

@@ -24,7 +24,6 @@ class GradReducer:
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.pending = None  # (flat, lo, hi)
-        self.total = None    # elements of the flat gradient buffer that will be reported (None: unknown, only full buckets go out early)
         self.comm_stream = None
         self.launched = []   # (lo, hi) ranges reduced in this backward (for tests/inspection)
         # RCCL averages inside the collective (ncclAvg): saves a read-modify-write pass over the 694 MB of gradients that
@@ -80,9 +79,7 @@ class GradReducer:
             assert f is flat and phi == lo, "gradient slices must be reported contiguously in order"
             self.pending = (flat, plo, hi)
         f, plo, phi = self.pending
-        # a full bucket goes out; so does anything finished once less than a bucket is left to come (`total` elements in all, set by the
-        # wrapper): the last slices are the ones nothing can hide, so they should not wait for each other
-        if phi - plo >= self.bucket_elems or (self.total is not None and self.total - phi < self.bucket_elems):
+        if phi - plo >= self.bucket_elems:
             self._launch(f, plo, phi)
             self.pending = (flat, phi, phi)
 
