@@ -1,5 +1,6 @@
 """Repro harness for an intermittent mismatch between the plain backward and the FIRST backward under DataParallelTokenizer (world 1, RCCL):
-N times {fresh tiny model, plain step, wrap, first wrapped step, compare every gradient}, per setting."""
+N times {fresh tiny model, plain step, wrap, first wrapped step, compare every gradient}, per setting.  VT_REPRO_BUCKET=<bytes>: the
+reducer's bucket size (1024 = every stage's slice is reduced the moment it is final)."""
 import gc
 import os
 import sys
@@ -41,7 +42,7 @@ for label, env in (("default (stream, tail, early flush)", {}), ("VT_WGRAD_STREA
     for i in range(N):
         model, _ = build(cfg, seed=7 + i)
         plain = run(model, model)
-        dp = DataParallelTokenizer(model, bucket_bytes=8 << 20)
+        dp = DataParallelTokenizer(model, bucket_bytes=int(os.environ.get('VT_REPRO_BUCKET', 8 << 20)))
         got = run(model, dp)
         bad = {n: float((plain[n] - got[n]).abs().max()) for n in plain if not torch.equal(plain[n], got[n])}
         if bad:
