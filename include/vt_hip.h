@@ -457,6 +457,17 @@ int vt_tokenizer_set_wgrad_batch(vtTokenizer* tk, int32_t n);
 int vt_tokenizer_backward(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
                           void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t stage_end,
                           int32_t* final_through, vtStream stream);
+/* Data-parallel runs (ABI 8).  on != 0: a collective's workgroups share the chip with the backward (DistributedDataParallel's bucketed
+ * all-reduce, trainers/base_trainer.py:388), so the backward's GEMMs with more 192x192 tiles than CUs are launched one tile per workgroup
+ * (vtGemmNT.tile = 6) and the hardware hands tiles to whichever CU is free.  Bit-identical gradients.  (ABI 7 tied this to
+ * vt_tokenizer_set_wgrad_tail(n > 0).) */
+int vt_tokenizer_set_data_parallel(vtTokenizer* tk, int32_t on);
+/* vt_tokenizer_backward for a caller that reduces finished gradient slices between stages (ABI 8): runs stages from stage_begin until
+ * *final_through advances (a group of weight gradients was flushed) or the last stage is done; *stage_next = the stage to go on with
+ * (== vt_tokenizer_num_backward_stages() when the backward is complete).  ~8 calls per backward at 12 + 12 blocks instead of 27. */
+int vt_tokenizer_backward_until_flush(vtTokenizer* tk, const vtTokenizerTensors* params, const float* d_pred, const float* gscal,
+                                      void* workspace, const vtTokenizerTensors* grads, int32_t stage_begin, int32_t* stage_next,
+                                      int32_t* final_through, vtStream stream);
 
 /* ------------------------------------------------------------------------------------------
  * A stack of timm Blocks on its own (fp32 [B, L, D] in and out): `transformer_encoder_parallel` / `_fused` called

@@ -317,7 +317,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.vt_abi_version() == 7
+    assert lib.vt_abi_version() == 8
     # argument validation runs on the host before any launch: bad arguments give a code and a message, no GPU needed
     p = vt.hip.GemmNT()
     assert lib.vt_gemm_nt(ctypes.byref(p), None) == -1

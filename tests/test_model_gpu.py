@@ -153,12 +153,34 @@ def test_data_parallel_wrapper_single_rank_rccl():
 
         plain = run(model)
         dp = DataParallelTokenizer(model, bucket_bytes=8 << 20)
-        red = model._engine.reducer
+        red, eng = model._engine.reducer, model._engine
+        assert red.early_release and eng.wgrad_stream is not None and eng.wgrad_tail == 3 and eng.data_parallel
+        stage_of = None
+
+        def report(a, b):
+            """every differing gradient with the backward stage that writes it and its slice of the flat buffer"""
+            nonlocal stage_of
+            if stage_of is None:
+                stage_of = {n: st_ for n, _, st_ in eng.order}
+            return [(n, stage_of[n], eng.grad_offsets[n], float((a[n] - b[n]).abs().max())) for n in a if not torch.equal(a[n], b[n])]
+
+        for bucket in (8 << 20, 1024):       # 1024: every slice goes to its collective the moment the engine reports it
+            red.bucket_elems = bucket // 4
+            for rep in range(2):
+                wrapped = run(dp)
+                total = sum(p.numel() for p in model.parameters())
+                assert red.launched and red.launched[0][0] == 0 and red.launched[-1][1] == total
+                assert all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:])) and len(red.launched) >= 3
+                bad = report(plain, wrapped)
+                assert not bad, (bucket, rep, len(bad), bad[:12])
+        # late writers, deterministically (one run, no timing luck needed): every slice is snapshotted behind a device-wide
+        # synchronisation at the moment it is REPORTED final; at world size 1 nothing may change it afterwards
+        red.check_late_writers = True
         wrapped = run(dp)
-        assert red.launched and red.launched[0][0] == 0 and red.launched[-1][1] == sum(p.numel() for p in model.parameters())
-        assert all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:])) and len(red.launched) >= 3
-        bad = {n: float((plain[n] - wrapped[n]).abs().max()) for n in plain if not torch.equal(plain[n], wrapped[n])}
-        assert not bad, (len(bad), list(bad.items())[:12])
+        late = red.check_snapshots(eng.flat_grad)
+        red.check_late_writers = False
+        assert not late, late
+        assert not report(plain, wrapped)
         model._engine.reducer = None
     finally:
         if created:

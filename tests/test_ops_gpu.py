@@ -363,6 +363,44 @@ def test_gemm_nt_split_k_is_deterministic_and_close_to_the_unsplit_kernel(hip, M
 
 
 @pytest.mark.gpu
+def test_gemm_nt_split_k_hand_off_under_uneven_concurrent_load(hip):
+    """The split-K hand-off (write-through partial tiles, an arrival counter, the last arriver reads every partial back past its L2) is the one
+    cross-workgroup exchange inside the tokenizer's backward at one or two clips per GPU -- and under data parallelism it runs NEXT TO the
+    side stream's weight-gradient launches and the collective, not alone on the chip (the round-4 record has one unexplained gradient
+    mismatch in exactly that setting).  The CDNA4 guide's rule for such exchanges: test them under UNEVEN load, checking every word.  Here
+    60 launches of the one-clip shapes run while a second stream keeps part of the chip busy with copies and a grouped weight-gradient GEMM
+    of changing size; every output must equal the first quiet run bit for bit and the counters must be back at zero."""
+    torch.manual_seed(0)
+    side = torch.cuda.Stream()
+    big_src = torch.randn(64 << 20, device="cuda")
+    big_dst = torch.empty_like(big_src)
+    dy = bf(_rand((1536, 768), 71)).cuda()
+    xx = bf(_rand((1536, 3072), 72)).cuda()
+    wg = torch.empty(768, 3072, device="cuda")
+    ws = hip.splitk_workspace(torch.device("cuda", 0))
+    shapes = [(128, 768, 3072, hip.EPI_BF16), (1536, 768, 3072, hip.EPI_F32), (1536, 768, 2304, hip.EPI_BF16), (3072, 768, 3072, hip.EPI_BF16)]
+    for M, N, K, epi in shapes:
+        a, b = bf(_rand((M, K), 900 + M)).cuda(), bf(_rand((N, K), 901 + K)).cuda()
+        quiet = hip.gemm_nt(a, b, epi=epi, splitk=None).clone()
+        torch.cuda.synchronize()
+        outs = [torch.empty_like(quiet) for _ in range(60)]
+        go = torch.cuda.Event()
+        go.record()
+        side.wait_event(go)
+        with torch.cuda.stream(side):
+            for i in range(12):                      # uneven: bursts of HBM traffic, then a matrix-bound launch, then nothing
+                big_dst[: (8 << 20) * (1 + i % 4)].copy_(big_src[: (8 << 20) * (1 + i % 4)])
+                if i % 3 == 0:
+                    hip.gemm_tn_grouped([dict(A=dy, B=xx, out=wg, p_lim=768, q_lim=3072)])
+        for o in outs:
+            hip.gemm_nt(a, b, epi=epi, splitk=None, out=o)
+        torch.cuda.synchronize()
+        diff = [i for i, o in enumerate(outs) if not torch.equal(o, quiet)]
+        assert not diff, (M, N, K, epi, diff[:8], float((outs[diff[0]].float() - quiet.float()).abs().max()))
+        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.gpu
 def test_gemm_nt192_gelu_table_equals_the_arithmetic_on_every_bf16_magnitude(hip):
     """The 192x192 kernel's fc1 epilogue looks gelu(u) up in an LDS table of the bf16 patterns with |u| in [2^-16, 16) and falls back to
     the arithmetic for a 4-column group that holds anything else; the 128x128 kernel keeps the arithmetic.  B = identity rows, so u is

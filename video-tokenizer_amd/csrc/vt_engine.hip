@@ -100,6 +100,7 @@ struct vtTokenizer {
     bool splitk_on = !g_no_splitk;           // vt_tokenizer_set_split_k / vt_stack_set_split_k; VT_GEMM_SPLITK=0 starts it off
     int wg_batch = 4;                        // vt_tokenizer_set_wgrad_batch: blocks per grouped weight-gradient launch (1..WG_BATCH)
     int wg_tail = 0;                         // vt_tokenizer_set_wgrad_tail: the encoder's first wg_tail blocks (the LAST of the backward) flush their weight gradients block by block
+    bool data_parallel = false;              // vt_tokenizer_set_data_parallel: a collective runs next to the backward (see nt())
     bool in_backward = false;                // set by the entry points: nt() hands the split-K workspace to backward GEMMs only
     size_t splitk = 0, splitk_bytes = 0;     // vt_gemm_nt's split-K partial sums + arrival counters (zeroed by *_init_workspace)
     // bf16 gradient operands that a block's weight-gradient GEMMs read.  The wgrads of WG_BATCH consecutive blocks are
@@ -276,10 +277,16 @@ extern "C" int vt_tokenizer_set_wgrad_stream(vtTokenizer* t, vtStream side) {
 // the last backward kernel, fully exposed.  With n > 0 the encoder's blocks below n are flushed block by block (n = 3: groups 3-2 | 1 | 0),
 // which leaves one block's 28 MB for the tail and costs three launches that do not fill whole rounds of the chip (+ ~0.1 ms of compute).
 // Same kernels on the same operands: gradients are bit-identical to the default schedule.
-// n > 0 also marks the handle as data-parallel for nt(): the backward's multi-round GEMMs then go out one tile per workgroup.
 extern "C" int vt_tokenizer_set_wgrad_tail(vtTokenizer* t, int32_t n) {
     VT_CHECK_ARG(t && n >= 0, "vt_tokenizer_set_wgrad_tail: null handle or negative count");
     t->wg_tail = n;
+    return VT_OK;
+}
+// Data-parallel runs: a gradient all-reduce's persistent workgroups hold CUs during the backward; nt() then launches the backward's
+// GEMMs that have more 192x192 tiles than the chip has CUs one tile per workgroup (vtGemmNT.tile = 6).  Same bits.
+extern "C" int vt_tokenizer_set_data_parallel(vtTokenizer* t, int32_t on) {
+    VT_CHECK_ARG(t, "vt_tokenizer_set_data_parallel: null handle");
+    t->data_parallel = on != 0;
     return VT_OK;
 }
 // blocks per grouped weight-gradient launch, 1..4 (default 4: 768 tiles = three whole rounds of the chip).  Smaller groups hand the gradient
@@ -379,12 +386,13 @@ static vtGemmNT nt(const vtTokenizer* t, void* ws, const void* A, int64_t lda, c
     // backward only: the forward pass of a clip stays bit-identical whatever batch it runs in (sampled token ids, reconstructions);
     // its gradients already differ across batch sizes in the last fp32 bits (summation over the batch's rows)
     if (t->splitk_bytes && t->in_backward && t->splitk_on) { p.splitk_ws = WS(void, t->splitk); p.splitk_ws_bytes = (int64_t)t->splitk_bytes; }
-    // data-parallel runs (wg_tail > 0 marks them): launches of several exact rounds of 192x192 tiles go out one tile per workgroup instead of
-    // as 256 persistent workgroups with fixed tile lists.  Equal speed on a free chip (62.9 vs 63.2 us on fc1 forward); with a collective's
-    // workgroups holding CUs the hardware dispatcher hands the remaining tiles to whichever CU is free (4 rounds -> 5), where a persistent
-    // workgroup that could not start runs its whole list after the others have finished theirs (x 1.67 measured, tools/cu_thief_stats.sh)
+    // data-parallel runs (vt_tokenizer_set_data_parallel): launches with more 192x192 tiles than one round of the chip go out one tile per
+    // workgroup instead of as 256 persistent workgroups with fixed tile lists.  Equal speed on a free chip (62.9 vs 63.2 us on fc1 forward,
+    // measured at whole rounds: 768 / 1024 tiles); with a collective's workgroups holding CUs the hardware dispatcher hands the remaining
+    // tiles to whichever CU is free (4 rounds -> 5), where a persistent workgroup that could not start runs its whole list after the
+    // others have finished theirs (x 1.67 measured with a single-GPU stand-in, tools/cu_thief_stats.sh -- not yet under a real collective)
     // (backward only: that is where the gradient all-reduce runs, and the forward's GELU launch would fill its look-up table once per tile)
-    if (t->wg_tail > 0 && t->in_backward && M % 192 == 0 && N % 192 == 0 && (long)(M / 192) * (N / 192) > 256) p.tile = 6;
+    if (t->data_parallel && t->in_backward && M % 192 == 0 && N % 192 == 0 && (long)(M / 192) * (N / 192) > 256) p.tile = 6;
     return p;
 }
 
@@ -817,6 +825,28 @@ extern "C" int vt_tokenizer_backward(vtTokenizer* t, const vtTokenizerTensors* P
     }
     if (final_through) *final_through = t->final_through;
     VT_CHECK_LAUNCH("vt_tokenizer_backward");
+    return VT_OK;
+}
+
+// The same, for a caller that reduces finished gradient slices between stages (parallel.GradReducer): runs stages from stage_begin until
+// *final_through advances (a group of weight gradients was flushed) or the last stage is done, and returns the stage to go on with in
+// *stage_next.  One call per reported slice (~8 per backward at 12 + 12 blocks) instead of one per stage (27): the host side of the
+// reference's own recipe, one clip per GPU under data parallelism, is what this shortens.
+extern "C" int vt_tokenizer_backward_until_flush(vtTokenizer* t, const vtTokenizerTensors* P, const float* d_pred, const float* gscal, void* ws,
+                                                 const vtTokenizerTensors* G, int32_t stage_begin, int32_t* stage_next, int32_t* final_through,
+                                                 vtStream s) {
+    VT_CHECK_ARG(t && stage_next && final_through, "vt_tokenizer_backward_until_flush: null pointer");
+    const int nstage = vt_tokenizer_num_backward_stages(t);
+    VT_CHECK_ARG(stage_begin >= 0 && stage_begin < nstage, "vt_tokenizer_backward_until_flush: bad first stage");
+    const int before = stage_begin == 0 ? 0 : t->final_through;
+    int st = stage_begin;
+    int32_t ft = before;
+    do {
+        TRY(vt_tokenizer_backward(t, P, d_pred, gscal, ws, G, st, st + 1, &ft, s));
+        ++st;
+    } while (st < nstage && ft == before);
+    *stage_next = st;
+    *final_through = ft;
     return VT_OK;
 }
 

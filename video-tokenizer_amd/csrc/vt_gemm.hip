@@ -541,7 +541,7 @@ static void launch_skinny(const vtGemmNT& p, hipStream_t s) {
 constexpr int VT_SPLITK_CTR_BYTES = 4096;   // arrival counters (one per 128x128 output tile) in front of the partial sums
 extern "C" size_t vt_gemm_nt_splitk_workspace_bytes(void) { return VT_SPLITK_CTR_BYTES + (size_t)512 * BM * BN * 4; }   // automatic rule: tiles x split <= 2 x 256
 
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half);
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile);
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst);
 int vt_gemm192_init();
 extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
@@ -604,9 +604,9 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant == 6 ? 5 : g_gemm_variant >= 17 ? g_gemm_variant - 1 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
+        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant >= 17 ? g_gemm_variant - 1 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
         const int half = g_gemm_variant == 5;
-        vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half);
+        vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half, g_gemm_variant == 6);
         VT_CHECK_LAUNCH("vt_gemm_nt(192)");
         return VT_OK;
     }

@@ -1012,16 +1012,18 @@ static int g_num_cus = 256;   // set by vt_gemm192_init from the device properti
 
 // Called by vt_gemm_nt / vt_gemm_tn_grouped (vt_gemm.hip) after argument validation.
 template <int WN>
-static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg) {
+static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg, int one_tile) {
     using G = NTGeo<WN>;
     NT192Args a;
     a.p = p;
     a.dbg = dbg;
     a.tiles_m = (p.M + TM - 1) / TM;
     a.tiles_n = (p.N + G::TNW - 1) / G::TNW;
-    // WN == 4: persistent, one workgroup per CU walks tiles b, b + grid, ... (dbg 5 = one tile per workgroup, for A/B timing)
+    // WN == 4: persistent, one workgroup per CU walks tiles b, b + grid, ...; one_tile (vtGemmNT.tile = 6, the data-parallel backward): one
+    // tile per workgroup, so that the hardware dispatcher hands tiles to whichever CU is free while a collective's workgroups hold some.
+    // A launch mode, not a timing ablation: `dbg` stays 0 and every epilogue keeps its production store path
     const int ntiles = a.tiles_m * a.tiles_n;
-    const int persist = (WN == 4 && dbg != 5) ? g_num_cus : ntiles;
+    const int persist = (WN == 4 && !one_tile) ? g_num_cus : ntiles;
     const dim3 grid(ntiles < persist ? ntiles : persist), block(G::THREADS);
     const size_t lds = G::NST * G::STAGE;
     constexpr size_t tab_gelu = WN == 4 ? GeluTab<VT_EPI_BF16_GELU>::BYTES : 0;
@@ -1034,9 +1036,9 @@ static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg) {
 }
 
 // half == 0: 192x192 tiles, one workgroup per CU; half != 0: 192x96 tiles, two per CU
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half) {
-    if (half) launch_nt192<2>(p, s, dbg);
-    else launch_nt192<4>(p, s, dbg);
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile) {
+    if (half) launch_nt192<2>(p, s, dbg, one_tile);
+    else launch_nt192<4>(p, s, dbg, one_tile);
     return 0;
 }
 

@@ -131,6 +131,7 @@ class TokenizerEngine:
         self.wgrad_tail = 0   # set_wgrad_tail(): flush the encoder's first blocks' weight gradients block by block (data-parallel runs)
         self.wgrad_batch = 0    # set_wgrad_batch(): blocks per grouped weight-gradient launch (0 = the library's 4)
         self.wgrad_stream = None   # set_wgrad_stream(): torch.cuda.Stream the deferred weight-gradient launches run on (data-parallel runs)
+        self.data_parallel = False  # set_data_parallel(): a collective shares the chip with the backward (one tile per workgroup for its multi-round GEMMs)
         self.graph_mode = False   # GraphedStep: weights are re-packed inside the captured step, the VQ seed counter lives on the device
 
     def __deepcopy__(self, memo):
@@ -216,8 +217,17 @@ class TokenizerEngine:
                 hip.check(hip.lib().vt_tokenizer_set_wgrad_stream(st.handle, self.wgrad_stream.cuda_stream), "vt_tokenizer_set_wgrad_stream")
             if self.wgrad_batch:
                 hip.check(hip.lib().vt_tokenizer_set_wgrad_batch(st.handle, self.wgrad_batch), "vt_tokenizer_set_wgrad_batch")
+            if self.data_parallel:
+                hip.check(hip.lib().vt_tokenizer_set_data_parallel(st.handle, 1), "vt_tokenizer_set_data_parallel")
             self.states[key] = st
         return st
+
+    def set_data_parallel(self, on):
+        """A collective's workgroups will hold CUs during the backward (vt_tokenizer_set_data_parallel): its GEMMs with more tiles than
+        the chip has CUs go out one tile per workgroup.  Bit-identical gradients."""
+        self.data_parallel = bool(on)
+        for st in self.states.values():
+            hip.check(hip.lib().vt_tokenizer_set_data_parallel(st.handle, int(self.data_parallel)), "vt_tokenizer_set_data_parallel")
 
     def set_wgrad_batch(self, n):
         """Blocks per grouped weight-gradient launch, 1..4 (vt_tokenizer_set_wgrad_batch; the library's default is 4).  Bit-identical gradients."""
@@ -361,15 +371,24 @@ class TokenizerFunction(torch.autograd.Function):
         saved = {n: engine.grad_views[n].clone() for n in aliased}
         final = ctypes.c_int32(0)
         done = 0
-        # without a reducer the whole backward is one enqueue; with one, stage by stage so finished slices can be reduced
-        chunks = [(s_, s_ + 1) for s_ in range(st.nstages)] if red is not None else [(0, st.nstages)]
-        for lo_s, hi_s in chunks:
+        # without a reducer the whole backward is one enqueue; with one, the engine runs until the next group of weight gradients is
+        # flushed (a slice of the flat buffer becomes final), the slice goes to the reducer, and so on: ~8 calls at 12 + 12 blocks
+        if red is None:
             hip.check(lib.vt_tokenizer_backward(st.handle, ctypes.byref(ps.struct), hip.ptr(d_pred), hip.ptr(gscal), hip.ptr(st.ws),
-                                                ctypes.byref(engine.grad_struct.struct), lo_s, hi_s, ctypes.byref(final), hip.stream()),
+                                                ctypes.byref(engine.grad_struct.struct), 0, st.nstages, ctypes.byref(final), hip.stream()),
                       "vt_tokenizer_backward")
-            while red is not None and done < final.value:  # stages whose gradients are final (deferred wgrads flushed)
-                red.segment_ready(engine.flat_grad, *engine.segments[done])
-                done += 1
+        else:
+            if getattr(red, "early_release", False):
+                red.total = max(hi for _, hi in engine.segments.values())    # the reducer lets the last slices go as they are reported
+            nxt, stage = ctypes.c_int32(0), 0
+            while stage < st.nstages:
+                hip.check(lib.vt_tokenizer_backward_until_flush(st.handle, ctypes.byref(ps.struct), hip.ptr(d_pred), hip.ptr(gscal), hip.ptr(st.ws),
+                                                                ctypes.byref(engine.grad_struct.struct), stage, ctypes.byref(nxt), ctypes.byref(final),
+                                                                hip.stream()), "vt_tokenizer_backward_until_flush")
+                stage = nxt.value
+                while done < final.value:  # stages whose gradients are final (deferred weight gradients flushed)
+                    red.segment_ready(engine.flat_grad, *engine.segments[done])
+                    done += 1
         if red is not None:
             red.finish()
         grads = []

@@ -178,6 +178,8 @@ ENGINE_SIGNATURES = {
     "vt_tokenizer_set_wgrad_batch": (c_i32, [c_vp, c_i32]),
     "vt_stack_set_split_k": (c_i32, [c_vp, c_i32]),
     "vt_tokenizer_backward": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, c_i32, ctypes.POINTER(c_i32), c_vp]),
+    "vt_tokenizer_set_data_parallel": (c_i32, [c_vp, c_i32]),
+    "vt_tokenizer_backward_until_flush": (c_i32, [c_vp, _TT, c_vp, c_vp, c_vp, _TT, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp]),
 }
 
 

@@ -18,13 +18,50 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+class _HipStreams:
+    """The reducer's stream plumbing on the device: events, waits and the collective itself.  Kept apart from the bucket logic so
+    that tests/test_engine_ledger_cpu.py can run the SAME `GradReducer` against a recording stand-in and check, without a GPU, that
+    every writer of a slice happens-before the collective that reads it."""
+
+    def __init__(self, device, process_group, use_avg, world):
+        self.device, self.pg, self.use_avg, self.world = device, process_group, use_avg, world
+
+    def current(self):
+        return torch.cuda.current_stream(self.device)
+
+    def new_stream(self):
+        return torch.cuda.Stream(device=self.device)
+
+    def record(self, stream, timing=False):
+        ev = torch.cuda.Event(enable_timing=timing)
+        ev.record(stream)
+        return ev
+
+    def wait(self, stream, event):
+        stream.wait_event(event)
+
+    def wait_stream(self, stream, other):
+        stream.wait_stream(other)
+
+    def all_reduce(self, stream, view):
+        with torch.cuda.stream(stream):
+            if self.use_avg:
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
+            else:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+                view.mul_(1.0 / self.world)
+
+
 class GradReducer:
-    def __init__(self, process_group=None, bucket_bytes=64 << 20):
+    def __init__(self, process_group=None, bucket_bytes=64 << 20, early_release=True):
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
+        self.early_release = early_release   # once less than a bucket is left to come, finished slices go out as they are reported
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.pending = None  # (flat, lo, hi)
+        self.total = None    # elements that will be reported in one backward (set by the engine); None: only full buckets go out early
         self.comm_stream = None
+        self.streams = None  # _HipStreams, made at the first device-side launch (tests substitute a recording one)
         self.launched = []   # (lo, hi) ranges reduced in this backward (for tests/inspection)
         # RCCL averages inside the collective (ncclAvg): saves a read-modify-write pass over the 694 MB of gradients that
         # would compete with the backward kernels for HBM; gloo (CPU tests) has no AVG, so sum then scale there
@@ -36,33 +73,34 @@ class GradReducer:
         self.record_events = False
         self.events = []      # [(start, stop)] per launched bucket of the last backward
         self.compute_done = None
+        self._alive = []      # the ordering events of this backward: kept until the next backward starts (never destroyed while a wait is queued)
+        # debugging aid (tests/test_parallel_gpu.py; the advisor's round-4 suggestion): with check_late_writers set, every reported slice is
+        # snapshotted behind a device-wide synchronisation BEFORE its collective is enqueued; check_snapshots() after the backward names
+        # every slice that a kernel still wrote after the engine had reported it final (world size 1: the collective changes no value)
+        self.check_late_writers = False
+        self._snapshots = []
 
     def _launch(self, flat, lo, hi):
         if hi <= lo:
             return
         view = flat[lo:hi]
-        if flat.is_cuda:
+        if self.streams is None and flat.is_cuda:
+            self.streams = _HipStreams(flat.device, self.pg, self.use_avg, self.world)
+        st = self.streams
+        if st is not None:
             if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=flat.device)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(flat.device))  # slice fully written by kernels enqueued so far
-            self.comm_stream.wait_event(ev)
+                self.comm_stream = st.new_stream()
+            ev = st.record(st.current())               # slice fully written by the kernels enqueued on the compute stream so far
+            st.wait(self.comm_stream, ev)
+            self._alive.append(ev)
             if self.extra_stream is not None:
-                ev2 = torch.cuda.Event()
-                ev2.record(self.extra_stream)
-                self.comm_stream.wait_event(ev2)
-            with torch.cuda.stream(self.comm_stream):
-                if self.record_events:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(self.comm_stream)
-                if self.use_avg:
-                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg)
-                else:
-                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
-                    view.mul_(1.0 / self.world)
-                if self.record_events:
-                    e1.record(self.comm_stream)
-                    self.events.append((e0, e1))
+                ev2 = st.record(self.extra_stream)     # ... and by the weight-gradient launches enqueued on the side stream so far
+                st.wait(self.comm_stream, ev2)
+                self._alive.append(ev2)
+            e0 = st.record(self.comm_stream, timing=True) if self.record_events else None
+            st.all_reduce(self.comm_stream, view)
+            if self.record_events:
+                self.events.append((e0, st.record(self.comm_stream, timing=True)))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
             view.mul_(1.0 / self.world)
@@ -73,15 +111,27 @@ class GradReducer:
         if self.pending is None:
             self.launched = []
             self.events = []
+            self._alive = []
+            self._snapshots = []
             self.pending = (flat, lo, hi)
         else:
             f, plo, phi = self.pending
             assert f is flat and phi == lo, "gradient slices must be reported contiguously in order"
             self.pending = (flat, plo, hi)
+        if self.check_late_writers and flat.is_cuda:
+            torch.cuda.synchronize(flat.device)
+            self._snapshots.append((lo, hi, flat[lo:hi].clone()))
         f, plo, phi = self.pending
-        if phi - plo >= self.bucket_elems:
+        # a full bucket goes out; so does anything finished once less than a bucket is left to come (`total` elements in all): the
+        # last slices are the ones no later backward kernel can hide, so they do not wait for each other
+        if phi - plo >= self.bucket_elems or (self.total is not None and self.total - phi < self.bucket_elems):
             self._launch(f, plo, phi)
             self.pending = (flat, phi, phi)
+
+    def check_snapshots(self, flat):
+        """[(lo, hi, differing elements)] for every reported slice whose content changed after it was reported (see check_late_writers)"""
+        torch.cuda.synchronize(flat.device)
+        return [(lo, hi, int((flat[lo:hi] != snap).sum())) for lo, hi, snap in self._snapshots if not torch.equal(flat[lo:hi], snap)]
 
     def finish(self):
         """Flush the tail bucket and order the compute stream after every collective."""
@@ -89,11 +139,11 @@ class GradReducer:
             f, plo, phi = self.pending
             self._launch(f, plo, phi)
             self.pending = None
-            if f.is_cuda and self.comm_stream is not None:
+            if self.streams is not None and self.comm_stream is not None:
+                st = self.streams
                 if self.record_events:
-                    self.compute_done = torch.cuda.Event(enable_timing=True)
-                    self.compute_done.record(torch.cuda.current_stream(f.device))   # behind the last backward kernel
-                torch.cuda.current_stream(f.device).wait_stream(self.comm_stream)
+                    self.compute_done = st.record(st.current(), timing=True)   # behind the last backward kernel
+                st.wait_stream(st.current(), self.comm_stream)
 
 
 class DataParallelTokenizer(nn.Module):
@@ -125,6 +175,8 @@ class DataParallelTokenizer(nn.Module):
         # first three blocks one group at a time (3-2 | 1 | 0) so that slice is one block's 28 MB instead of four blocks' 113 MB
         # (vt_tokenizer_set_wgrad_tail; VT_WGRAD_TAIL=0 keeps the single-GPU schedule)
         module._engine.set_wgrad_tail(int(os.environ.get("VT_WGRAD_TAIL", "3")))
+        # a collective's workgroups will hold CUs during the backward: its multi-round GEMMs go out one tile per workgroup (engine.set_data_parallel)
+        module._engine.set_data_parallel(os.environ.get("VT_DP_ONE_TILE", "1") != "0")
         if os.environ.get("VT_WGRAD_BATCH"):   # blocks per grouped weight-gradient launch (1..4, default 4): smaller groups report finished
             module._engine.set_wgrad_batch(int(os.environ["VT_WGRAD_BATCH"]))   # slices sooner; measured neutral on compute with the second stream
         # the deferred weight-gradient launches on a stream of their own (vt_tokenizer_set_wgrad_stream; VT_WGRAD_STREAM=0 = single stream).
