@@ -123,13 +123,44 @@ def time_attention_kernels(B, c, reps=20):
     return tf * 1e6, tb * 1e6, 12.0 * L * L * D * B / (tf + tb) / 1e12
 
 
+def time_vq_forward(B, c, reps=20):
+    """The codebook search the north star names (`vt_vq_forward`: normalise, nearest code over the whole codebook on the exact-fp32 MFMA, gather,
+    straight-through output, loss partials -- the N x K score matrix is never materialised) replayed at the step's shape through the C ABI and
+    timed with HIP events on its stream, in the training default (mode 2: sampling) and the deterministic mode 0.  algorithmic flops = 2 N K d;
+    algorithmic HBM bytes = z in + codebook once + indices + q out = 4 N d + 4 K d + 8 N + 4 N d."""
+    import video_tokenizer_amd.hip as hip
+    N, K, d = B * c["bottleneck_token_num"], c["codebook_size"], c["bottleneck_dim"]
+    z = torch.randn(N, 64, device="cuda")
+    cb = torch.randn(K, d, device="cuda")
+    out = {"N": N, "K": K, "d": d, "algorithmic_bytes": 4 * N * d + 4 * K * d + 8 * N + 4 * N * d, "algorithmic_flops": 2 * N * K * d,
+           "peak_fp32_matrix_TFLOPs": 157.3, "note": "whole forward quantizer call (prep + search + finalize kernels); compute-bound by construction: "
+           "the GB/s figure is algorithmic bytes / time as the north star asks, not a bandwidth the kernel is limited by"}
+    for mode, name in ((2, "sample"), (0, "argmin")):
+        for _ in range(3):
+            hip.vq_forward(z, cb, mode, inv_tau=1.0 / 0.03, seed=1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            hip.vq_forward(z, cb, mode, inv_tau=1.0 / 0.03, seed=2 + i)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        out[name] = {"us": round(t * 1e6, 1), "TFLOPs_fp32": round(out["algorithmic_flops"] / t / 1e12, 1), "GBps_algorithmic": round(out["algorithmic_bytes"] / t / 1e9, 1),
+                     "frac_of_fp32_matrix_peak": round(out["algorithmic_flops"] / t / 1e12 / 157.3, 3)}
+    return out
+
+
+MEASURED_MFMA_CEILING_TFLOPS = 1742.0    # bare 192x192 MFMA pattern with its LDS fragment reads and a barrier per K-tile, random data, all 256 CUs
+MEASURED_MFMA_CEILING_SOURCE = "profiles/r04_mfma_probe_larger_tile.log"
+
+
 def committed_profile(kind):
     """Figures that cannot be collected inside this process (rocprofv3 runs around it), read from the newest record under profiles/:
     kind 'mfma_busy' -> whole-step MFMA-pipe busy fraction (tools/pmc_step.sh); kind 'in_step_us' -> the dominant kernel's average
     duration inside the traced step (rocprofv3 --kernel-trace --stats of this script)."""
     import csv
     import glob
-    for r in (4, 3, 2, 1):
+    for r in (5, 4, 3, 2, 1):
         if kind == "mfma_busy":
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0{r}_pmc_mfma_busy_step*.json"))):
                 with open(path) as f:
@@ -167,14 +198,23 @@ def torch_yardstick(batch):
     return None
 
 
+def _traffic_path():
+    return next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
+
+
 def measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from PMC counters (cannot be collected inside this process):
-    the rocprofv3 passes of tools/pmc_traffic.sh, committed under profiles/."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm_nt192.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
+    the rocprofv3 passes of tools/pmc_traffic.sh, committed under profiles/ (`traffic_source` names the file)."""
+    path = _traffic_path()
     if path is None:
         return None
     with open(path) as f:
         return int(json.load(f)["traffic_bytes_per_launch_mean"])
+
+
+def traffic_source():
+    path = _traffic_path()
+    return None if path is None else os.path.relpath(path, ROOT) + " (committed rocprofv3 --pmc record, not collected in this run)"
 
 
 def fsq_autoencoder_step(vt, name, steps, warmup, clips=4):
@@ -543,6 +583,10 @@ def main():
                 ach, per, _ = time_dominant_kernel(B, c)
                 res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt192_kernel<VT_EPI_BF16> (qkv fwd + fc1/proj/qkv dgrad)", "achieved": round(ach, 1),
                                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
+                                   "traffic_source": traffic_source(),
+                                   # against what a bare MFMA loop of this tile pattern sustains on this chip under its own power management
+                                   "frac_of_measured_mfma_ceiling": {"value": round(ach / MEASURED_MFMA_CEILING_TFLOPS, 4), "ceiling_TFLOPs": MEASURED_MFMA_CEILING_TFLOPS,
+                                                                     "source": MEASURED_MFMA_CEILING_SOURCE},
                                    "per_shape": per, "whole_step_frac": round(clips_s / world * f_clip / 1e12 / PEAK_BF16_TFLOPS, 4)}
                 # the north star's own figures next to it: the attention kernels against the same peak (live), the dominant kernel's
                 # average INSIDE a traced step and the whole-step MFMA-pipe busy fraction (both from the committed rocprofv3 records)
@@ -550,6 +594,7 @@ def main():
                 res["roofline"]["attention_frac"] = round(attn_tf / PEAK_BF16_TFLOPS, 4)
                 res["roofline"]["attention"] = {"achieved": round(attn_tf, 1), "unit": "TFLOP/s", "us_forward": round(us_f, 1), "us_backward": round(us_b, 1),
                                                 "flops": "12 L^2 D per clip and layer (forward 4, backward 8; the two recompute kernels execute 7 products)"}
+                res["roofline"]["vq_search"] = time_vq_forward(B, c)
                 res["roofline"]["in_step_avg_us"] = committed_profile("in_step_us")
                 res["roofline"]["mfma_busy_step"] = committed_profile("mfma_busy")
             except Exception as e:  # noqa: BLE001

@@ -351,6 +351,26 @@ def _grads_of(model, x, w, q_weight):
     return out, {n: p.grad.clone() for n, p in model.named_parameters()}
 
 
+# Full-size parity bars: (forward rel-L2 of pred_frames / encoded / projected_z, rel-L2 of EVERY parameter gradient) against the bf16-emulating
+# oracle that follows the device's indices.  Set at ~2 x what the final round-5 build measures (profiles/r05_gpu_tests.log: forward
+# 2.5e-3 ... 4.6e-3, worst gradient 5.5e-3 ... 9.1e-3), not at "what passes": a kernel change that doubles an error fails here.
+FULL_SIZE_TOL = {"B": (1e-2, 2e-2), "C": (1e-2, 2e-2), "D": (1e-2, 2e-2), "E": (1e-2, 2e-2)}
+
+
+def _record_parity(name, B, fwd, worst, agree, loss_rel):
+    import json
+    import os
+    rec = {"config": name, "clips": B, **{k: round(v, 6) for k, v in fwd.items()}, "loss_q_rel": round(loss_rel, 7), "indices_equal": round(agree, 5),
+           "worst_gradients": [(n, round(e, 6)) for n, e in worst]}
+    print("PARITY " + json.dumps(rec))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_measured.jsonl", "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
 def _full_size_forward_backward_parity(name, B, seed, clip_seed, query_std=1.0):
     """One config of BASELINE.json at its OWN size, train(), mode L, forward AND backward through the fused engine against the
     bf16-emulating CPU oracle that follows the GPU's indices: every parameter gradient."""
@@ -379,13 +399,17 @@ def _full_size_forward_backward_parity(name, B, seed, clip_seed, query_std=1.0):
     assert float((d_gpu - d_free).max()) < 2e-2, float((d_gpu - d_free).max())   # differing indices are near ties
 
     assert set(out.keys()) == set(ref.keys())
-    assert rel(out["pred_frames"].cpu(), ref["pred_frames"].detach()) < 2e-2
-    assert rel(out["encoded"].cpu(), ref["encoded"].detach()) < 2e-2
-    assert rel(out["projected_z"].cpu(), ref["projected_z"].detach()) < 2e-2
-    np.testing.assert_allclose(out["loss_q"].item(), ref["loss_q"].item(), rtol=2e-2)
+    fwd = {k: rel(out[k].cpu(), ref[k].detach()) for k in ("pred_frames", "encoded", "projected_z")}
     bad = [(n, rel(grads[n].cpu(), p[n].grad)) for n in grads]
+    worst = sorted(bad, key=lambda t: -t[1])[:3]
+    # what was measured, on success too (pytest -rP shows it; profiles/r05_gpu_tests.log keeps it): a regression shows as a number first
+    _record_parity(name, B, fwd, worst, agree, float(abs(out["loss_q"].item() - ref["loss_q"].item()) / abs(ref["loss_q"].item())))
+    tol_fwd, tol_grad = FULL_SIZE_TOL[name]
+    for k, e in fwd.items():
+        assert e < tol_fwd, (k, e, tol_fwd)
+    np.testing.assert_allclose(out["loss_q"].item(), ref["loss_q"].item(), rtol=2e-2)
     assert len(bad) == len(list(model.parameters())) and all(p[n].grad is not None for n in grads)
-    assert all(e < 6e-2 for _, e in bad), sorted(bad, key=lambda t: -t[1])[:6]
+    assert all(e < tol_grad for _, e in bad), (tol_grad, sorted(bad, key=lambda t: -t[1])[:6])
 
 
 def test_config_B_full_size_forward_backward_matches_oracle():
