@@ -160,9 +160,19 @@ def test_single_stream_schedule_has_no_cross_stream_access(lg, host_on_ledger, g
     assert not bad, bad
 
 
-@pytest.mark.parametrize("geom", list(GEOMS))
-@pytest.mark.parametrize("bucket", [64 << 20, 8 << 20, 1024])
-@pytest.mark.parametrize("side,tail", [(True, 3), (False, 3), (True, 0), (False, 0)])
+def _dp_cases():
+    out = []
+    for geom in GEOMS:
+        for bucket in (64 << 20, 8 << 20, 1024):
+            for side, tail in ((True, 3), (False, 3), (True, 0), (False, 0)):
+                # the headline geometry builds a 173 M-parameter model per case: the shipped schedule and the plain one, largest and smallest bucket
+                if geom == "B" and not ((side, tail) in ((True, 3), (False, 0)) and bucket != 8 << 20):
+                    continue
+                out.append(pytest.param(geom, bucket, side, tail, id=f"{geom}-bucket{bucket}-side{int(side)}-tail{tail}"))
+    return out
+
+
+@pytest.mark.parametrize("geom,bucket,side,tail", _dp_cases())
 def test_data_parallel_schedule_orders_every_conflicting_access(lg, host_on_ledger, geom, bucket, side, tail):
     """Two steps under the reducer.  bucket 1024 = every slice goes to the collective the moment the engine reports it: the strongest
     form of the early release that round 4 took out after one unexplained mismatch."""

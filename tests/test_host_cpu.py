@@ -417,7 +417,7 @@ def test_plain_c_client_links_against_the_c_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
-    assert lines[0] == "abi 7"
+    assert lines[0] == "abi 8"
     assert lines[1].startswith("gemm_nt rc -1 msg vt_gemm_nt: null operand")
     assert lines[2].startswith("create rc 0 stages 5 ws ") and int(lines[2].split()[-1]) > 1 << 20
     assert lines[3].startswith("bad create rc -1") and "head_dim" in lines[3]

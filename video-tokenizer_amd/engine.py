@@ -429,7 +429,13 @@ class GraphedStep:
             loss, out = graphed(x)                                # replay; `loss` and the kept outputs are static buffers, valid until the next replay
             opt.step()                                            # do NOT set grads to None in between (zero_grad(set_to_none=False) or nothing)
 
-    Single process only: a data-parallel reducer (parallel.DataParallelTokenizer) is not captured."""
+    Single process only: a data-parallel reducer (parallel.DataParallelTokenizer) is not captured.
+
+    self_check (default on) runs loss_fn for two eager steps and four replays on two clips and requires bit equality, so loss_fn must be a pure
+    function of (out, x) and the module's parameters: a loss with state of its own that advances per call (the discriminator's spectral-norm power
+    iteration, a global_step counter, an adaptive-weight EMA) either fails the check spuriously or has its state advanced six times before
+    training starts -- snapshot / restore that state around the constructor or pass self_check=False and verify the first replays yourself.
+    The check leaves every .grad pointing at the flat buffer's views holding its LAST replay's gradients; the first real replay overwrites them."""
 
     def __init__(self, model, x, loss_fn, warmup=2, outputs=("bottleneck_rep", "loss_q", "loss_commit", "loss_codebook"), self_check=True):
         eng = model._engine
@@ -528,7 +534,8 @@ class GraphedStep:
             raise RuntimeError("GraphedStep self-check failed -- the captured step does not reproduce the eager step:\n  " + "\n  ".join(bad[:6]) +
                                "\nOn this ROCm build replays read stale scalars under the runtime's graph packet capture: set "
                                "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the process touches the GPU (importing video_tokenizer_amd "
-                               "first does it), or train with the eager step (DESIGN 6b)")
+                               "first does it), or train with the eager step (DESIGN 6b).  (A loss_fn with state of its own that advances per call fails "
+                               "this check by construction: see the class docstring, self_check=False.)")
 
     def _step(self):
         self.ctr.add_(1)

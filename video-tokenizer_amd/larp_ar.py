@@ -597,6 +597,12 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
     n_rest = max_new_tokens - 1
     if use_graph is None:
         use_graph = os.environ.get("VT_AR_GRAPH", "1") != "0"
+    if use_graph and os.environ.get("VT_AR_GRAPH") != "1":
+        # a replayed decode step reads device scalars written by earlier nodes of the same replay (position, sampled token): exactly the
+        # pattern that went stale under the runtime's graph packet capture.  Unless the switch is known to be off, stay eager
+        # (VT_AR_GRAPH=1 insists).
+        import video_tokenizer_amd as _pkg
+        use_graph = _pkg.graph_replay_safe()
     use_graph = use_graph and n_rest >= GRAPH_MIN_STEPS
     graphs = {}
     for i in range(n_rest):
