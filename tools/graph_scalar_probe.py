@@ -1,4 +1,4 @@
-"""Root cause probe for the stale 0-dim read inside replayed graphs (DESIGN 6b, round-3 tools/graph_debug4/6.py).
+"""Root cause probe for the stale 0-dim read inside replayed graphs (found in round 3).
 
 Hypothesis: a torch elementwise kernel reads a 0-dim operand through the SCALAR cache (s_load: the address is wave-uniform); the
 producer wrote it with vector stores from another CU.  Between ordinary launches the runtime's kernel-start acquire invalidates the

@@ -456,7 +456,7 @@ class GraphedStep:
         eng.graph_mode = True
         self.state.graphed = True
         # What the caller gets back.  (1) The LOSS VALUE is recomputed by ordinary launches after the replay (same ops, same bits as
-        # eager; ~6 tiny kernels).  Measured on this ROCm build (tools/graph_debug4.py, graph_debug6.py): inside a replayed graph a torch
+        # eager; ~6 tiny kernels).  Measured on this ROCm build (round 3; the probe that remains is tools/graph_scalar_probe.py): inside a replayed graph a torch
         # elementwise kernel that reads a 0-dim tensor written by an earlier node of the same replay can see the value a previous replay
         # left at that address -- `loss = a + 0.1 * b` came out as 1.0 + 0.1 * b, 1.0 being the backward seed that had reused `a`'s block
         # -- depending on which single-workgroup kernels ran in between (a `torch.equal` outside was enough).  Every kernel of this
