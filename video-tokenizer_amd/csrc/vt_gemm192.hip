@@ -1133,6 +1133,158 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192d_kernel(const NT192Args a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, four waves (timing prototype)
+// gemm_nt192w4_kernel (vtGemmNT.tile = 20, plain bf16 epilogue only): the same 192 x 192 x 64 tile and ring with FOUR waves, one per SIMD, each
+// owning 96 x 96 outputs (6 x 6 accumulators = 144 registers of the 512 a lone wave may hold).  Why: round 5 found the K loop LDS-bound -- per
+// K-tile and CU the LDS-DMA writes 48 KB (~870 array cycles at the ~56 B/clk that path sustains) and the eight 96 x 48 waves read 144 KB of
+// fragments back (576 cycles): 1446 array cycles next to 1152 matrix-pipe cycles.  A 96 x 96 wave tile reads (96 + 96) x 128 B x 4 waves = 96 KB
+// (384 cycles): 1254.  The price: a lone wave has no partner to cover its 12 DMA pieces and 24 fragment reads per K-tile; they are dealt two
+// reads and two pieces per MFMA row.  Epilogue: 8-byte stores straight from the MFMA layout (a prototype for the main loop's speed; tile time over
+// K gives the per-K-tile cost).
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt192w4_kernel(const NT192Args a) {
+    static_assert(EPI == VT_EPI_BF16, "prototype: plain bf16 epilogue");
+    constexpr int OPA = TM * TK * 2, STAGE = 2 * OPA, NST = 3, P = 12;     // 12 DMA pieces per thread and K-tile (6 A + 6 B)
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    const vtGemmNT& p = a.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = a.tiles_m * a.tiles_n;
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* B = (const bf16_t*)p.B;
+    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const int fr = lane & 15, fq = lane >> 4;
+    const int arow = wm * 96 + fr, brow = wn * 96 + fr;
+    const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4);
+    const unsigned b_off0 = OPA + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
+    unsigned poff[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int i = k % 6;
+        const int slot = i * 256 + tid;
+        const int row = slot >> 3;
+        const int lc = (slot & 7) ^ ((row >> 1) & 7);
+        poff[k] = (unsigned)((row * (k < 6 ? p.lda : p.ldb) + lc * 8) * 2);
+    }
+    const int nt = p.K / TK;
+    auto piece = [&](const bf16_t* ap, const bf16_t* bp, unsigned dst, int k) {
+        const int i = k % 6;
+        glds16_sv(k < 6 ? ap : bp, poff[k], dst + (k < 6 ? 0 : OPA) + (i * 256 + wave * 64) * 16);
+    };
+#define VT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // the MFMAs are inline asm with the accumulator pinned to the AGPR class ("+a"): as builtins hipcc moved 108 accumulator registers to the
+    // VGPR file and back around every first half (216 v_accvgpr copies + 51 s_nop per K-tile)
+#define VT_ROW6(accrow, bb, aa)                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accrow[j_]) : "v"(bb[j_]), "v"(aa)); \
+    __builtin_amdgcn_sched_barrier(0)
+    for (int it = blockIdx.x; it < nwg; it += (int)gridDim.x) {
+        const int sid = xcd_remap(it, nwg);
+        const int m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * TN_;
+        const bf16_t* Ap = A + (int64_t)m0 * p.lda;
+        const bf16_t* Bp = B + (int64_t)n0 * p.ldb;
+        if (it != (int)blockIdx.x) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+            if (t < nt) {
+#pragma unroll
+                for (int k = 0; k < P; ++k) piece(Ap + t * TK, Bp + t * TK, sbase + t * STAGE, k);
+            }
+        if (nt > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (nt > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();
+        f32x4 acc[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 xa[6], xb[6], ya[6], yb[6];
+        {
+            const unsigned na0 = sbase + a_off0, nb0 = sbase + b_off0;
+            VT_DSR(xb[0], nb0, 0); VT_DSR(xb[1], nb0, 2048); VT_DSR(xb[2], nb0, 4096); VT_DSR(xb[3], nb0, 6144); VT_DSR(xb[4], nb0, 8192); VT_DSR(xb[5], nb0, 10240);
+            VT_DSR(xa[0], na0, 0); VT_DSR(xa[1], na0, 2048); VT_DSR(xa[2], na0, 4096); VT_DSR(xa[3], na0, 6144); VT_DSR(xa[4], na0, 8192); VT_DSR(xa[5], na0, 10240);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int slot = 0;
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) {
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            const unsigned cur = sbase + slot * STAGE, nx = sbase + nslot * STAGE;
+            {   // first half: k-step 0 out of x, k-step 1 of this K-tile into y (two reads per MFMA row)
+                const unsigned na1 = (cur + a_off0) ^ 64u, nb1 = (cur + b_off0) ^ 64u;
+                VT_DSR(yb[0], nb1, 0); VT_DSR(yb[1], nb1, 2048);
+                VT_ROW6(acc[0], xb, xa[0]);
+                VT_DSR(yb[2], nb1, 4096); VT_DSR(yb[3], nb1, 6144);
+                VT_ROW6(acc[1], xb, xa[1]);
+                VT_DSR(yb[4], nb1, 8192); VT_DSR(yb[5], nb1, 10240);
+                VT_ROW6(acc[2], xb, xa[2]);
+                VT_DSR(ya[0], na1, 0); VT_DSR(ya[1], na1, 2048);
+                VT_ROW6(acc[3], xb, xa[3]);
+                VT_DSR(ya[2], na1, 4096); VT_DSR(ya[3], na1, 6144);
+                VT_ROW6(acc[4], xb, xa[4]);
+                VT_DSR(ya[4], na1, 8192); VT_DSR(ya[5], na1, 10240);
+                VT_ROW6(acc[5], xb, xa[5]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t + 1 < nt) {
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            raw_barrier();
+            {   // second half: k-step 1 out of y, k-step 0 of the next K-tile into x, the 12 DMA pieces of K-tile t + 3 two per MFMA row
+                const unsigned na0 = nx + a_off0, nb0 = nx + b_off0;
+                const bool dma = t + NST < nt;
+                const bf16_t* ap = Ap + (t + NST) * TK;
+                const bf16_t* bp = Bp + (t + NST) * TK;
+                VT_DSR(xb[0], nb0, 0); VT_DSR(xb[1], nb0, 2048);
+                if (dma) { piece(ap, bp, cur, 0); piece(ap, bp, cur, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                VT_ROW6(acc[0], yb, ya[0]);
+                VT_DSR(xb[2], nb0, 4096); VT_DSR(xb[3], nb0, 6144);
+                if (dma) { piece(ap, bp, cur, 2); piece(ap, bp, cur, 3); }
+                __builtin_amdgcn_sched_barrier(0);
+                VT_ROW6(acc[1], yb, ya[1]);
+                VT_DSR(xb[4], nb0, 8192); VT_DSR(xb[5], nb0, 10240);
+                if (dma) { piece(ap, bp, cur, 4); piece(ap, bp, cur, 5); }
+                __builtin_amdgcn_sched_barrier(0);
+                VT_ROW6(acc[2], yb, ya[2]);
+                VT_DSR(xa[0], na0, 0); VT_DSR(xa[1], na0, 2048);
+                if (dma) { piece(ap, bp, cur, 6); piece(ap, bp, cur, 7); }
+                __builtin_amdgcn_sched_barrier(0);
+                VT_ROW6(acc[3], yb, ya[3]);
+                VT_DSR(xa[2], na0, 4096); VT_DSR(xa[3], na0, 6144);
+                if (dma) { piece(ap, bp, cur, 8); piece(ap, bp, cur, 9); }
+                __builtin_amdgcn_sched_barrier(0);
+                VT_ROW6(acc[4], yb, ya[4]);
+                VT_DSR(xa[4], na0, 8192); VT_DSR(xa[5], na0, 10240);
+                if (dma) { piece(ap, bp, cur, 10); piece(ap, bp, cur, 11); }
+                __builtin_amdgcn_sched_barrier(0);
+                VT_ROW6(acc[5], yb, ya[5]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot = nslot;
+        }
+        // prototype epilogue: 8-byte stores from the MFMA layout (the MFMAs are asm: their results need the wait states hipcc would have added)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int m = m0 + wm * 96 + i * 16 + fr, n = n0 + wn * 96 + j * 16 + fq * 4;
+                f32x4 v = acc[i][j];
+                if (p.bias) v += *(const f32x4*)(p.bias + n);
+                *(bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            }
+    }
+#undef VT_DSR
+#undef VT_ROW6
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 struct TN192Args {
     vtGemmTN p[VT_TN_MAX_GROUP];
@@ -1537,6 +1689,17 @@ int vt_gemm_nt192d_launch(const vtGemmNT& p, hipStream_t s, int one_tile) {
     return 0;
 }
 
+int vt_gemm_nt192w4_launch(const vtGemmNT& p, hipStream_t s) {
+    NT192Args a;
+    a.p = p;
+    a.dbg = 0;
+    a.tiles_m = p.M / TM;
+    a.tiles_n = p.N / TN_;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL((gemm_nt192w4_kernel<VT_EPI_BF16>), dim3(ntiles < g_num_cus ? ntiles : g_num_cus), dim3(256), 3 * STAGE_BYTES, s, a);
+    return 0;
+}
+
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst) {
     TN192Args a;
     a.n = n;
@@ -1582,6 +1745,7 @@ int vt_gemm192_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192d_kernel<VT_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<4>::NST * NTGeo<4>::STAGE + NT192D_EXTRA);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192d_kernel<VT_EPI_BF16_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<4>::NST * NTGeo<4>::STAGE + NT192D_EXTRA);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192d_kernel<VT_EPI_BF16_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<4>::NST * NTGeo<4>::STAGE + NT192D_EXTRA);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192w4_kernel<VT_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
     if (e == hipSuccess) {
