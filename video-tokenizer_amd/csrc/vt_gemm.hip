@@ -542,17 +542,13 @@ constexpr int VT_SPLITK_CTR_BYTES = 4096;   // arrival counters (one per 128x128
 extern "C" size_t vt_gemm_nt_splitk_workspace_bytes(void) { return VT_SPLITK_CTR_BYTES + (size_t)512 * BM * BN * 4; }   // automatic rule: tiles x split <= 2 x 256
 
 int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile);
-bool vt_gemm_nt192d_eligible(const vtGemmNT& p);
-int vt_gemm_nt192d_launch(const vtGemmNT& p, hipStream_t s, int one_tile);
-int vt_gemm192_num_cus();
-int vt_gemm_nt192w4_launch(const vtGemmNT& p, hipStream_t s);
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst);
 int vt_gemm192_init();
 extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
     const int g_gemm_variant = p.tile;   // per call (vtGemmNT.tile); the library holds no tile setting of its own
-    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 20, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192 with the epilogue behind each tile, 19 = 192x192 with the epilogue inside the next tile's K loop (K = 768, whole tiles), 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4/17/18 timing ablations)", g_gemm_variant);
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 18, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4/17/18 timing ablations)", g_gemm_variant);
     VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
@@ -608,22 +604,6 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        // vtGemmNT.tile = 19: the K = 768 kernel that runs tile i's epilogue inside tile i + 1's K loop (gemm_nt192d_kernel).  Bit-identical
-        // outputs; measured level with the kernel below on the plain epilogue and behind it with GELU / gelu' (DESIGN section 5, round 5), so
-        // the automatic choice never takes it.
-        if (g_gemm_variant == 20) {   // four-wave timing prototype (round 5): whole tiles, plain bf16 epilogue
-            VT_CHECK_ARG(p.epi == VT_EPI_BF16 && p.M % 192 == 0 && p.N % 192 == 0 && (int64_t)192 * p.lda * 2 < (1ll << 31) && (int64_t)192 * p.ldb * 2 < (1ll << 31),
-                         "vt_gemm_nt: tile 20 needs the plain bf16 epilogue and M, N multiples of 192");
-            vt_gemm_nt192w4_launch(p, (hipStream_t)stream);
-            VT_CHECK_LAUNCH("vt_gemm_nt(192, four waves)");
-            return VT_OK;
-        }
-        if (g_gemm_variant == 19) {
-            VT_CHECK_ARG(vt_gemm_nt192d_eligible(p), "vt_gemm_nt: tile 19 needs K = 768, M and N multiples of 192 and a bf16 epilogue");
-            vt_gemm_nt192d_launch(p, (hipStream_t)stream, 0);
-            VT_CHECK_LAUNCH("vt_gemm_nt(192, deferred epilogue)");
-            return VT_OK;
-        }
         const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant >= 17 ? g_gemm_variant - 1 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
         const int half = g_gemm_variant == 5;
         vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half, g_gemm_variant == 6);

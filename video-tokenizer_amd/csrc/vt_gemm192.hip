@@ -663,627 +663,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     }   // tile loop
 }
 
-// ------------------------------------------------------------------------------------------------ NT, deferred epilogue
-// gemm_nt192d_kernel: the 192x192x64 kernel above for the step's K = 768 launches with several output tiles per workgroup (qkv
-// forward, fc1 forward + GELU, fc2 input gradient x gelu'): the epilogue of output tile i runs INSIDE the K loop of tile i + 1.
-//
-// Why: a third to a half of a K = 768 tile's cycles lay outside its main loop (stamps, DESIGN section 5: accumulators -> LDS image,
-// read-back, GELU / gelu' arithmetic, stores, the ring drained and refilled around it), with the matrix pipe idle and every CU in
-// the same phase.  The staged image (74 KB) cannot stay in the LDS next to the ring (144 KB) and a second accumulator set does not
-// fit the registers -- but the OUTPUT does: 72 fp32 accumulators leave as 36 registers of bf16 (bias added, rounded: `held`), and
-// what freed them is a register pipeline over k-STEPS (two 36-register fragment sets, one per 32-wide half of a K-tile, instead of
-// two 72-register sets for whole K-tiles).  Per K-tile body: the first half's MFMAs run while the second half's fragments are
-// read, then the barrier that publishes the next K-tile, then the second half's MFMAs with the next K-tile's first fragments and
-// the LDS-DMA of K-tile + 3 into the slot just vacated.  The finished tile leaves one twelfth per body: a 16-row x 192-column block
-// (rows i*16.. of wave row b & 1) is written by its four owner waves into one of two 6-KB staging images behind the ring in the
-// first half, the body's barrier publishes it, and in the second half 384 threads read it back row-major -- 16 bytes each, a wave
-// instruction = 1 KB of whole lines -- apply GELU (arithmetic: the look-up table does not fit next to two staging images) and
-// store with streaming stores.  (First version: 8-byte stores straight from the MFMA layout, 16 rows x 32 bytes per instruction.
-// Correct and SLOWER than the kernel above -- 57.0 / 85.5 us on qkv forward / fc1 GELU against 51.4 / 76.8 -- although the same K
-// loop without any epilogue ran in 47.1 / 62.4: partial-line stores cost far more than their bytes; as streaming stores 69.5 / 188.)
-// gelu' is applied by the owner waves before staging (their lanes' own rows: the column sums for the fc1 bias gradient stay a
-// per-lane running sum, reduced once per tile), with the saved pre-activations loaded two bodies ahead in the MFMA layout.
-// The ring never drains between output tiles: K-tiles 0..2 of the next tile are requested in bodies 9..11 of the current one.
-// Same MFMA order per accumulator as the kernels above: bit-identical outputs.
-//
-// vmcnt is counted at RUN time: `issued` counts this wave's vector-memory instructions (LDS-DMA pieces, epilogue stores, bias
-// and pre-activation loads), `mark[slot]` remembers its value behind the DMA of the K-tile in that slot, and the wait in front of a
-// barrier is s_waitcnt vmcnt(issued - mark) through a scalar jump table -- no hand-derived immediates to get wrong when an epilogue
-// changes what it issues.  (A smaller count than necessary only waits longer; the table clamps at 20.)
-__device__ __forceinline__ void vm_wait_dyn(int n) {   // s_waitcnt vmcnt(min(n, 20)), n wave-uniform
-#define VT_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n < 0 ? 0 : n > 20 ? 20 : n) {
-        VT_VMW(0) VT_VMW(1) VT_VMW(2) VT_VMW(3) VT_VMW(4) VT_VMW(5) VT_VMW(6) VT_VMW(7) VT_VMW(8) VT_VMW(9) VT_VMW(10)
-        VT_VMW(11) VT_VMW(12) VT_VMW(13) VT_VMW(14) VT_VMW(15) VT_VMW(16) VT_VMW(17) VT_VMW(18) VT_VMW(19) VT_VMW(20)
-    }
-#undef VT_VMW
-}
-
-// vector-memory accesses with a wave-uniform 64-bit base + a per-lane 32-bit byte offset, invisible to the compiler's wait counting:
-// the caller counts them (`issued`) and waits by hand
-// timing ablations of the deferred epilogue (A/B builds, WRONG results except VT_D_PLAINST): -DVT_D_NOSTORE no global stores, -DVT_D_NOSTAGE no
-// staging writes / read-back, -DVT_D_PLAINST ordinary instead of streaming stores
-__device__ __forceinline__ void st16_sv_nt(const void* base_uniform, unsigned lane_off, bf16x8 v) {
-#ifdef VT_D_NOSTORE
-    asm volatile("" ::"v"(lane_off), "v"(v), "s"(base_uniform));
-    return;
-#endif
-#ifdef VT_D_PLAINST
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(base_uniform) : "memory");
-    return;
-#endif
-    // (s_nop 1: a VALU write to the data registers of a 16-byte store needs wait states the compiler does not add behind inline asm)
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void ld8_sv(bf16x4& dst, const void* base_uniform, unsigned lane_off) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void ld16_sv(f32x4& dst, const void* base_uniform, unsigned lane_off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void st4_sv(const void* base_uniform, unsigned lane_off, float v) {
-    asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off), "v"(v), "s"(base_uniform) : "memory");
-}
-// sum over the 16 lanes of a DPP row (fixed tree order); every lane of the row ends with the total
-__device__ __forceinline__ float row16_sum(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
-    return x;
-}
-
-// -DVT_D_NOUNITS (timing ablation, WRONG results): the K loop without the finished tile's epilogue
-#ifdef VT_D_NOUNITS
-#define VT_D_UNITS false
-#else
-#define VT_D_UNITS true
-#endif
-constexpr int NT192D_K = 768;                  // the only contraction length this kernel is built for (12 K-tiles per output tile)
-constexpr int NT192D_SROW = TN_ * 2 + 8;       // staging image row: 192 bf16 + 8 bytes (the 16 rows of a ds_write_b64 group fall on 16 bank pairs)
-constexpr int NT192D_SIMG = 16 * NT192D_SROW;  // one 16-row block
-constexpr int NT192D_EXTRA = 2 * NT192D_SIMG + 4 * TN_ * 4;   // two staging images + (DGELU) the two wave rows' column sums, one set per tile parity
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt192d_kernel(const NT192Args a) {
-    using G = NTGeo<4>;
-    constexpr int NT = NT192D_K / TK;     // 12 K-tiles = 12 bodies = the 12 (wave row, 16-row) blocks of the previous tile
-    static_assert(NT % G::NST == 0 && NT == 12, "a K-tile's ring slot must not depend on the output tile; one block per body");
-    extern __shared__ __attribute__((aligned(128))) char smem[];
-    const vtGemmNT& p = a.p;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int nwg = a.tiles_m * a.tiles_n;
-    const bf16_t* A = (const bf16_t*)p.A;
-    const bf16_t* B = (const bf16_t*)p.B;
-    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const int fr = lane & 15, fq = lane >> 4;
-    const int arow = wm * 96 + fr, brow = wn * 48 + fr;
-    const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4);
-    const unsigned b_off0 = G::OPA + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
-    unsigned poff[G::P];                 // every tile of this kernel lies inside the matrix: one set of lane offsets
-    nt192_piece_offsets<4>(p.lda, 0, TM, p.ldb, 0, TN_, tid, poff);
-    char* const stage = smem + G::NST * G::STAGE;                                   // [2][16][SROW]
-    [[maybe_unused]] float* const red0 = (float*)(stage + 2 * NT192D_SIMG);         // DGELU: [2 tile parities][2 wave rows][192] column sums
-    [[maybe_unused]] int ppar = 0;        // parity of the finished tile: its sums are read behind body 11's barrier while no barrier separates that from the next tile's first sums
-
-    int issued = 0, mark0 = 0, mark1 = 0, mark2 = 0;
-    auto issue_tile = [&](const bf16_t* ap, const bf16_t* bp, int kt, int slot) {
-        const unsigned dst = sbase + slot * G::STAGE;
-#pragma unroll
-        for (int k = 0; k < G::P; ++k) nt192_stage_piece<4>(ap + kt * TK, bp + kt * TK, poff, dst, k, wave);
-        issued += G::P;
-        if (slot == 0) mark0 = issued;
-        else if (slot == 1) mark1 = issued;
-        else mark2 = issued;
-    };
-    auto tile_coords = [&](int it, int& m0, int& n0) {
-        const int sid = xcd_remap(it, nwg);
-        m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * TN_;
-    };
-
-    // owner side of a block (MFMA layout): lane (fr, fq) of wave (wm, wn) holds row fr, columns wn*48 + j*16 + fq*4 .. + 3 of the block
-    const unsigned st_off = (unsigned)(fr * NT192D_SROW + (wn * 48 + fq * 4) * 2);                        // + j * 32 bytes
-    [[maybe_unused]] const unsigned voff_x = (unsigned)((fr * p.ldaux + wn * 48 + fq * 4) * 2);           // + j * 32 bytes (the saved pre-activations)
-    const unsigned voff_b = (unsigned)((wn * 48 + fq * 4) * 4);
-    // reader side: thread t < 384 takes 16 bytes: row t / 24, columns (t % 24) * 8 .. + 7 of the block
-    const int rd_row = tid / 24, rd_c = tid - rd_row * 24;
-    const bool reader = wave < 6;
-    const unsigned rd_off = (unsigned)(rd_row * NT192D_SROW + rd_c * 16);
-    const unsigned rd_o = (unsigned)((rd_row * p.ldo + rd_c * 8) * 2);
-    [[maybe_unused]] const unsigned rd_o2 = (unsigned)((rd_row * p.ldo2 + rd_c * 8) * 2);
-
-    // ---- state of the deferred epilogue
-    bf16x4 held[18];                      // the finished tile: accumulator (i, j) at 3 i + j; shifted down three per owned block
-    [[maybe_unused]] bf16x4 uq[3];        // DGELU: the pre-activations of this wave's next block, requested two bodies ahead
-    [[maybe_unused]] int marku = 0;
-    int pm0 = 0, pn0 = 0;                 // the finished tile's origin
-    bool proc = false;                    // a finished tile is waiting in `held`
-    bool red_pending = false;             // DGELU: both wave rows' column sums sit in `red`, to be added behind the next barrier
-    int rm0 = 0, rn0 = 0, rpar = 0;
-
-    // block `blk` (0..11: wave row blk & 1, rows (blk >> 1) * 16 .. + 15 of that wave row) of the finished tile
-    auto block_row0 = [&](int blk) { return (blk & 1) * 96 + (blk >> 1) * 16; };
-    // DGELU: request the pre-activations of block `blk` of the tile at (tm0, tn0) (owner waves)
-    auto request_u = [&](int tm0, int tn0, int blk) {
-        if constexpr (EPI == VT_EPI_BF16_DGELU) {
-            const char* base = (const char*)p.aux + ((int64_t)(tm0 + block_row0(blk)) * p.ldaux + tn0) * 2;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) ld8_sv(uq[j], base + j * 32, voff_x);
-            issued += 3;
-            marku = issued;
-        }
-    };
-    // The finished tile's block b leaves in SLICES placed between the MFMA rows of body b (a block of epilogue instructions in one gap
-    // stalls the matrix pipe: both waves of a SIMD run the same code in step).
-    // Owner waves, first half, slices 0..5: three accumulators (held[0..2]) -> staging image `buf`; gelu' applied on the way (DGELU).
-    auto own_step = [&](int sl, int buf, [[maybe_unused]] bool first_block) {
-        char* const img = stage + buf * NT192D_SIMG;
-        if constexpr (EPI == VT_EPI_BF16_DGELU) {
-            // twelve values, two per slice, one at a time (scheduling fences: interleaved evaluations keep ~25 temporaries alive)
-            const int j = sl >> 1, e0 = (sl & 1) * 2;
-#pragma unroll
-            for (int e = e0; e < e0 + 2; ++e) {
-                held[j][e] = f2bf(bf2f(held[j][e]) * gelu_erf_grad(bf2f(uq[j][e])));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (sl & 1) {
-                *(bf16x4*)(img + st_off + j * 32) = held[j];
-                // column sums of the rounded values (the fc1 bias gradient): the block's 16 rows by a fixed DPP tree, the wave row's six
-                // blocks one after the other in `red` (the same lanes own the same columns in every block: no other writer)
-                if (p.colsum_partial) {
-                    f32x4 v = {row16_sum(bf2f(held[j][0])), row16_sum(bf2f(held[j][1])), row16_sum(bf2f(held[j][2])), row16_sum(bf2f(held[j][3]))};
-                    if (fr == 0) {
-                        f32x4* dst = (f32x4*)(red0 + ppar * 2 * TN_ + wm * TN_ + wn * 48 + j * 16 + fq * 4);
-                        if (!first_block) v += *dst;
-                        *dst = v;
-                    }
-                }
-            }
-        } else {
-#ifndef VT_D_NOSTAGE
-            if (sl >= 1 && sl <= 3) *(bf16x4*)(img + st_off + (sl - 1) * 32) = held[sl - 1];
-#endif
-        }
-    };
-    auto own_done = [&]() {
-#pragma unroll
-        for (int q = 0; q < 15; ++q) held[q] = held[q + 3];
-    };
-    // Reader threads, second half, slices 0..5: 16 bytes of block `blk` out of staging image `buf` -> GELU (arithmetic, in place) -> global memory
-    bf16x8 rh;
-    auto rd_step = [&](int sl, int blk, int buf) {
-        if (!reader) return;
-        if (sl == 0) {
-#ifndef VT_D_NOSTAGE
-            const char* src = stage + buf * NT192D_SIMG + rd_off;
-            rh = cat4(*(const bf16x4*)src, *(const bf16x4*)(src + 8));
-#else
-            asm volatile("" : "=v"(rh));
-#endif
-        }
-        const int64_t row0 = pm0 + block_row0(blk);
-        if (sl == 1) {
-            st16_sv_nt((const char*)p.out + (row0 * p.ldo + pn0) * 2, rd_o, rh);
-            issued += 1;
-        }
-        if constexpr (EPI == VT_EPI_BF16_GELU) {
-            if (sl >= 1 && sl <= 4) {
-                const int e0 = (sl - 1) * 2;
-#pragma unroll
-                for (int e = e0; e < e0 + 2; ++e) {
-                    rh[e] = f2bf(gelu_erf(bf2f(rh[e])));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (sl == 5) {
-                st16_sv_nt((const char*)p.out2 + (row0 * p.ldo2 + pn0) * 2, rd_o2, rh);
-                issued += 1;
-            }
-        }
-    };
-    auto cs_finish = [&]() {      // behind a barrier that follows both wave rows' cs_to_lds
-        if constexpr (EPI == VT_EPI_BF16_DGELU) {
-            if (red_pending) {
-                if (wave < 3) {   // tid < 192: one column each, wave row 0 + wave row 1
-                    const float v = red0[rpar * 2 * TN_ + tid] + red0[rpar * 2 * TN_ + TN_ + tid];
-                    st4_sv(p.colsum_partial + (int64_t)(rm0 / TM) * p.N + rn0, (unsigned)tid * 4u, v);
-                    issued += 1;
-                }
-                red_pending = false;
-            }
-        }
-    };
-
-    // ---- prologue: K-tiles 0..2 of the first output tile
-    int m0, n0;
-    tile_coords(blockIdx.x, m0, n0);
-    const bf16_t* Ap = A + (int64_t)m0 * p.lda;
-    const bf16_t* Bp = B + (int64_t)n0 * p.ldb;
-    issue_tile(Ap, Bp, 0, 0);
-    issue_tile(Ap, Bp, 1, 1);
-    issue_tile(Ap, Bp, 2, 2);
-    vm_wait_dyn(issued - mark0);
-    raw_barrier();
-    bf16x8 xa[6], xb[3], ya[6], yb[3];    // fragments of k-step 0 (x) / k-step 1 (y) of a K-tile
-#define VT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define VT_ROW(accrow, bb, aa)                                                                   \
-    accrow[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[0], aa, accrow[0], 0, 0, 0);          \
-    accrow[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[1], aa, accrow[1], 0, 0, 0);          \
-    accrow[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[2], aa, accrow[2], 0, 0, 0);          \
-    __builtin_amdgcn_sched_barrier(0)
-    {
-        const unsigned na0 = sbase + a_off0, nb0 = sbase + b_off0;
-        VT_DSR(xb[0], nb0, 0); VT_DSR(xb[1], nb0, 2048); VT_DSR(xb[2], nb0, 4096);
-        VT_DSR(xa[0], na0, 0); VT_DSR(xa[1], na0, 2048); VT_DSR(xa[2], na0, 4096);
-        VT_DSR(xa[3], na0, 6144); VT_DSR(xa[4], na0, 8192); VT_DSR(xa[5], na0, 10240);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // One K-tile body; R = b % 3 is static: the ring slot of K-tile b.  The six LDS-DMA pieces of K-tile b + 3 go out one per MFMA row:
-    // three in this body's second half (the slot is free behind the barrier), three in the next body's first half.
-    const bf16_t *dpa = A, *dpb = B;      // the K-tile whose last three pieces are still to be issued
-    unsigned ddst = 0;
-    bool dpend = false;
-#define VT_DMA3(first)                                                                                                                 \
-    _Pragma("unroll") for (int k_ = (first); k_ < (first) + 3; ++k_) nt192_stage_piece<4>(dpa, dpb, poff, ddst, k_, wave);
-#define VT_DMA_A                                                                                                                       \
-    if (dpend) { VT_DMA3(3) issued += 3; }                                                                                             \
-    if (dpend) { if (PSLOT == 0) mark0 = issued; else if (PSLOT == 1) mark1 = issued; else mark2 = issued; }
-#define VT_DMA_B0 if (dpend) { VT_DMA3(0) issued += 3; }
-#define VT_DMA_B1
-#define VT_DMA_B2
-
-// The block's epilogue sits in ONE place per half body.  One slice per MFMA row instead (a scalar branch and a scheduling fence each) measured
-// slower: 53.6 / 64.2 / 89.8 / 105.0 us against 52.6 / 62.8 / 84.1 / 88.5 on qkv forward / fc1 plain / fc1 GELU / fc2 gelu'
-// (profiles/r05_gemm_deferred_epilogue.log); so did giving a body's twelve DMA pieces to one wave of every SIMD (54.7 against 51.3).
-#define VT_OWN(sl) if ((sl) == 3 && VT_D_UNITS && proc && owner) { _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) own_step(s_, b & 1, b < 2); }
-#define VT_RD(sl) if ((sl) == 3 && VT_D_UNITS && proc) { _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) rd_step(s_, b, b & 1); }
-#define VT_BODY(R, bexpr)                                                                                                              \
-    {                                                                                                                                  \
-        const int b = (bexpr);                                                                                                         \
-        constexpr int SLOT = (R), NSLOT = ((R) + 1) % 3, PSLOT = ((R) + 2) % 3;                                                        \
-        const unsigned cur = sbase + SLOT * G::STAGE, nx = sbase + NSLOT * G::STAGE;                                                   \
-        unsigned ao_ = a_off0, bo_ = b_off0;     /* opaque: the three bodies' fragment addresses are loop-invariant and would be hoisted (12 registers) */ \
-        asm volatile("" : "+v"(ao_), "+v"(bo_));                                                                                       \
-        const bool owner = wm == (b & 1);        /* this wave's rows are in block b of the finished tile */                            \
-        if constexpr (EPI != VT_EPI_BF16_DGELU) {                                                                                      \
-            if (b == NT - 3 && p.bias) {                                                                                               \
-                _Pragma("unroll") for (int j = 0; j < 3; ++j) ld16_sv(b4[j], (const char*)(p.bias + n0 + j * 16), voff_b);             \
-                issued += 3;                                                                                                           \
-                markb = issued;                                                                                                        \
-            }                                                                                                                          \
-        } else {                                                                                                                       \
-            if (VT_D_UNITS && proc && owner) {                                                                                         \
-                vm_wait_dyn(issued - marku);                                                                                           \
-                asm volatile("" : "+v"(uq[0]), "+v"(uq[1]), "+v"(uq[2]));                                                              \
-            }                                                                                                                          \
-        }                                                                                                                              \
-        /* ---- first half: k-step 0 out of x while k-step 1 of this K-tile goes into y; the owner waves stage block b */              \
-        {                                                                                                                              \
-            const unsigned na1 = (cur + ao_) ^ 64u, nb1 = (cur + bo_) ^ 64u;                                                           \
-            VT_DSR(yb[0], nb1, 0); VT_DSR(yb[1], nb1, 2048);                                                                           \
-            VT_ROW(acc[0], xb, xa[0]);                                                                                                 \
-            VT_DSR(yb[2], nb1, 4096); VT_DSR(ya[0], na1, 0);                                                                           \
-            VT_OWN(0);                                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[1], xb, xa[1]);                                                                                                 \
-            VT_DSR(ya[1], na1, 2048); VT_DSR(ya[2], na1, 4096);                                                                        \
-            VT_DMA_A                                                                                                                   \
-            VT_OWN(1);                                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[2], xb, xa[2]);                                                                                                 \
-            VT_DSR(ya[3], na1, 6144); VT_DSR(ya[4], na1, 8192);                                                                        \
-            VT_OWN(2);                                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[3], xb, xa[3]);                                                                                                 \
-            VT_DSR(ya[5], na1, 10240);                                                                                                 \
-            VT_OWN(3);                                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[4], xb, xa[4]);                                                                                                 \
-            VT_OWN(4);                                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[5], xb, xa[5]);                                                                                                 \
-            VT_OWN(5);                                                                                                                 \
-            if (VT_D_UNITS && proc && owner) {                                                                                         \
-                own_done();                                                                                                            \
-            }                                                                                                                          \
-            if constexpr (EPI == VT_EPI_BF16_DGELU) {                                                                                  \
-                /* the pre-activations of this wave's next block (two bodies on): of the finished tile while b <= 9, of THIS tile in   \
-                   its last two bodies (blocks 0 and 1 leave during the next tile's bodies 0 and 1, or first in the drain) */          \
-                if (owner && (b >= NT - 2 || proc)) {                                                                                  \
-                    if (b >= NT - 2) request_u(m0, n0, b - (NT - 2));                                                                  \
-                    else request_u(pm0, pn0, b + 2);                                                                                   \
-                }                                                                                                                      \
-            }                                                                                                                          \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        }                                                                                                                              \
-        /* ---- the next K-tile (this tile's b + 1, or the next tile's 0) and the staged block become visible; this K-tile's slot is free */ \
-        if (!(last && b == NT - 1)) vm_wait_dyn(issued - (NSLOT == 0 ? mark0 : NSLOT == 1 ? mark1 : mark2));                           \
-        raw_barrier();                                                                                                                 \
-        if (EPI == VT_EPI_BF16_DGELU && VT_D_UNITS && proc && b == NT - 1 && p.colsum_partial) { red_pending = true; rm0 = pm0; rn0 = pn0; rpar = ppar; }  \
-        cs_finish();        /* (both wave rows wrote their sums in front of this barrier: wave row 0 in body 10, wave row 1 in body 11) */ \
-        /* ---- second half: k-step 1 out of y, k-step 0 of the next K-tile into x, half the DMA of K-tile + 3, block b's read-back and stores */ \
-        {                                                                                                                              \
-            const unsigned na0 = nx + ao_, nb0 = nx + bo_;                                                                             \
-            dpend = true;                                                                                                              \
-            if (b + G::NST < NT) { dpa = Ap + (b + G::NST) * TK; dpb = Bp + (b + G::NST) * TK; }                                       \
-            else if (!last) { dpa = Apn + (b + G::NST - NT) * TK; dpb = Bpn + (b + G::NST - NT) * TK; }                                \
-            else dpend = false;                                                                                                        \
-            ddst = cur;                                                                                                                \
-            VT_DSR(xb[0], nb0, 0); VT_DSR(xb[1], nb0, 2048); VT_DSR(xb[2], nb0, 4096);                                                 \
-            VT_RD(0);                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[0], yb, ya[0]);                                                                                                 \
-            VT_DSR(xa[0], na0, 0); VT_DSR(xa[1], na0, 2048); VT_DSR(xa[2], na0, 4096);                                                 \
-            VT_RD(1);                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[1], yb, ya[1]);                                                                                                 \
-            VT_DSR(xa[3], na0, 6144); VT_DSR(xa[4], na0, 8192); VT_DSR(xa[5], na0, 10240);                                             \
-            VT_RD(2);                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[2], yb, ya[2]);                                                                                                 \
-            VT_DMA_B0                                                                                                                  \
-            VT_RD(3);                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[3], yb, ya[3]);                                                                                                 \
-            VT_DMA_B1                                                                                                                  \
-            VT_RD(4);                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[4], yb, ya[4]);                                                                                                 \
-            VT_DMA_B2                                                                                                                  \
-            VT_RD(5);                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-            VT_ROW(acc[5], yb, ya[5]);                                                                                                 \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        }                                                                                                                              \
-    }
-
-    for (int it = blockIdx.x; it < nwg; it += (int)gridDim.x) {
-        const bool last = it + (int)gridDim.x >= nwg;
-        int nm0 = 0, nn0 = 0;
-        if (!last) tile_coords(it + gridDim.x, nm0, nn0);
-        const bf16_t* Apn = A + (int64_t)nm0 * p.lda;
-        const bf16_t* Bpn = B + (int64_t)nn0 * p.ldb;
-        f32x4 acc[6][3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                typedef __attribute__((ext_vector_type(2))) float f32x2_;
-                f32x2_ lo, hi;
-                asm volatile("v_mov_b64 %0, 0" : "=v"(lo));
-                asm volatile("v_mov_b64 %0, 0" : "=v"(hi));
-                acc[i][j] = (f32x4){lo[0], lo[1], hi[0], hi[1]};
-            }
-        [[maybe_unused]] f32x4 b4[3];      // bias of this tile's columns, requested three bodies before its end
-        [[maybe_unused]] int markb = 0;
-#pragma unroll 1
-        for (int b3 = 0; b3 < NT; b3 += 3) {
-            VT_BODY(0, b3)
-            VT_BODY(1, b3 + 1)
-            VT_BODY(2, b3 + 2)
-        }
-        // ---- this tile is finished: its output waits in `held` (bias added, rounded) while the next tile's K loop runs
-        if constexpr (EPI != VT_EPI_BF16_DGELU) {
-            if (p.bias) {
-                vm_wait_dyn(issued - markb);   // (the DMA of the last three bodies stays in flight)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(b4[j]));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                f32x4 v = acc[i][j];
-                if constexpr (EPI != VT_EPI_BF16_DGELU) v += b4[j];
-                held[i * 3 + j] = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            }
-        pm0 = m0, pn0 = n0, proc = true;
-        if constexpr (EPI == VT_EPI_BF16_DGELU) ppar ^= 1;
-        m0 = nm0, n0 = nn0, Ap = Apn, Bp = Bpn;
-    }
-#undef VT_BODY
-#undef VT_OWN
-#undef VT_RD
-#undef VT_DMA3
-#undef VT_DMA_A
-#undef VT_DMA_B0
-#undef VT_DMA_B1
-#undef VT_DMA_B2
-#undef VT_DSR
-#undef VT_ROW
-    // ---- drain: the last tile's twelve blocks, with nothing left to hide them under (a barrier per block, two staging images in turn)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing of the ring is in flight any more: the drain counts nothing)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    raw_barrier();
-    cs_finish();
-#pragma unroll 1
-    for (int blk = 0; blk < NT; ++blk) {
-        if (wm == (blk & 1)) {
-            if constexpr (EPI == VT_EPI_BF16_DGELU) {
-                // blocks 0 and 1 were requested in the last two bodies of the K loop; the later ones of this wave row go out one block ahead
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("" : "+v"(uq[0]), "+v"(uq[1]), "+v"(uq[2]));
-            }
-#pragma unroll
-            for (int sl = 0; sl < 6; ++sl) own_step(sl, blk & 1, blk < 2);
-            own_done();
-            if constexpr (EPI == VT_EPI_BF16_DGELU) {
-                if (blk + 2 < NT) request_u(pm0, pn0, blk + 2);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();
-#pragma unroll
-        for (int sl = 0; sl < 6; ++sl) rd_step(sl, blk, blk & 1);
-    }
-    if constexpr (EPI == VT_EPI_BF16_DGELU) {
-        if (p.colsum_partial) { red_pending = true; rm0 = pm0; rn0 = pn0; rpar = ppar; }
-        cs_finish();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ NT, four waves (timing prototype)
-// gemm_nt192w4_kernel (vtGemmNT.tile = 20, plain bf16 epilogue only): the same 192 x 192 x 64 tile and ring with FOUR waves, one per SIMD, each
-// owning 96 x 96 outputs (6 x 6 accumulators = 144 registers of the 512 a lone wave may hold).  Why: round 5 found the K loop LDS-bound -- per
-// K-tile and CU the LDS-DMA writes 48 KB (~870 array cycles at the ~56 B/clk that path sustains) and the eight 96 x 48 waves read 144 KB of
-// fragments back (576 cycles): 1446 array cycles next to 1152 matrix-pipe cycles.  A 96 x 96 wave tile reads (96 + 96) x 128 B x 4 waves = 96 KB
-// (384 cycles): 1254.  The price: a lone wave has no partner to cover its 12 DMA pieces and 24 fragment reads per K-tile; they are dealt two
-// reads and two pieces per MFMA row.  Epilogue: 8-byte stores straight from the MFMA layout (a prototype for the main loop's speed; tile time over
-// K gives the per-K-tile cost).
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_nt192w4_kernel(const NT192Args a) {
-    static_assert(EPI == VT_EPI_BF16, "prototype: plain bf16 epilogue");
-    constexpr int OPA = TM * TK * 2, STAGE = 2 * OPA, NST = 3, P = 12;     // 12 DMA pieces per thread and K-tile (6 A + 6 B)
-    extern __shared__ __attribute__((aligned(128))) char smem[];
-    const vtGemmNT& p = a.p;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = a.tiles_m * a.tiles_n;
-    const bf16_t* A = (const bf16_t*)p.A;
-    const bf16_t* B = (const bf16_t*)p.B;
-    const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const int fr = lane & 15, fq = lane >> 4;
-    const int arow = wm * 96 + fr, brow = wn * 96 + fr;
-    const unsigned a_off0 = arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4);
-    const unsigned b_off0 = OPA + brow * 128 + ((fq ^ ((brow >> 1) & 7)) << 4);
-    unsigned poff[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        const int i = k % 6;
-        const int slot = i * 256 + tid;
-        const int row = slot >> 3;
-        const int lc = (slot & 7) ^ ((row >> 1) & 7);
-        poff[k] = (unsigned)((row * (k < 6 ? p.lda : p.ldb) + lc * 8) * 2);
-    }
-    const int nt = p.K / TK;
-    auto piece = [&](const bf16_t* ap, const bf16_t* bp, unsigned dst, int k) {
-        const int i = k % 6;
-        glds16_sv(k < 6 ? ap : bp, poff[k], dst + (k < 6 ? 0 : OPA) + (i * 256 + wave * 64) * 16);
-    };
-#define VT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-    // the MFMAs are inline asm with the accumulator pinned to the AGPR class ("+a"): as builtins hipcc moved 108 accumulator registers to the
-    // VGPR file and back around every first half (216 v_accvgpr copies + 51 s_nop per K-tile)
-#define VT_ROW6(accrow, bb, aa)                                                                  \
-    _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accrow[j_]) : "v"(bb[j_]), "v"(aa)); \
-    __builtin_amdgcn_sched_barrier(0)
-    for (int it = blockIdx.x; it < nwg; it += (int)gridDim.x) {
-        const int sid = xcd_remap(it, nwg);
-        const int m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * TN_;
-        const bf16_t* Ap = A + (int64_t)m0 * p.lda;
-        const bf16_t* Bp = B + (int64_t)n0 * p.ldb;
-        if (it != (int)blockIdx.x) __syncthreads();
-#pragma unroll
-        for (int t = 0; t < NST; ++t)
-            if (t < nt) {
-#pragma unroll
-                for (int k = 0; k < P; ++k) piece(Ap + t * TK, Bp + t * TK, sbase + t * STAGE, k);
-            }
-        if (nt > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (nt > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        raw_barrier();
-        f32x4 acc[6][6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 xa[6], xb[6], ya[6], yb[6];
-        {
-            const unsigned na0 = sbase + a_off0, nb0 = sbase + b_off0;
-            VT_DSR(xb[0], nb0, 0); VT_DSR(xb[1], nb0, 2048); VT_DSR(xb[2], nb0, 4096); VT_DSR(xb[3], nb0, 6144); VT_DSR(xb[4], nb0, 8192); VT_DSR(xb[5], nb0, 10240);
-            VT_DSR(xa[0], na0, 0); VT_DSR(xa[1], na0, 2048); VT_DSR(xa[2], na0, 4096); VT_DSR(xa[3], na0, 6144); VT_DSR(xa[4], na0, 8192); VT_DSR(xa[5], na0, 10240);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        int slot = 0;
-#pragma unroll 1
-        for (int t = 0; t < nt; ++t) {
-            const int nslot = slot == 2 ? 0 : slot + 1;
-            const unsigned cur = sbase + slot * STAGE, nx = sbase + nslot * STAGE;
-            {   // first half: k-step 0 out of x, k-step 1 of this K-tile into y (two reads per MFMA row)
-                const unsigned na1 = (cur + a_off0) ^ 64u, nb1 = (cur + b_off0) ^ 64u;
-                VT_DSR(yb[0], nb1, 0); VT_DSR(yb[1], nb1, 2048);
-                VT_ROW6(acc[0], xb, xa[0]);
-                VT_DSR(yb[2], nb1, 4096); VT_DSR(yb[3], nb1, 6144);
-                VT_ROW6(acc[1], xb, xa[1]);
-                VT_DSR(yb[4], nb1, 8192); VT_DSR(yb[5], nb1, 10240);
-                VT_ROW6(acc[2], xb, xa[2]);
-                VT_DSR(ya[0], na1, 0); VT_DSR(ya[1], na1, 2048);
-                VT_ROW6(acc[3], xb, xa[3]);
-                VT_DSR(ya[2], na1, 4096); VT_DSR(ya[3], na1, 6144);
-                VT_ROW6(acc[4], xb, xa[4]);
-                VT_DSR(ya[4], na1, 8192); VT_DSR(ya[5], na1, 10240);
-                VT_ROW6(acc[5], xb, xa[5]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (t + 1 < nt) {
-                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            raw_barrier();
-            {   // second half: k-step 1 out of y, k-step 0 of the next K-tile into x, the 12 DMA pieces of K-tile t + 3 two per MFMA row
-                const unsigned na0 = nx + a_off0, nb0 = nx + b_off0;
-                const bool dma = t + NST < nt;
-                const bf16_t* ap = Ap + (t + NST) * TK;
-                const bf16_t* bp = Bp + (t + NST) * TK;
-                VT_DSR(xb[0], nb0, 0); VT_DSR(xb[1], nb0, 2048);
-                if (dma) { piece(ap, bp, cur, 0); piece(ap, bp, cur, 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                VT_ROW6(acc[0], yb, ya[0]);
-                VT_DSR(xb[2], nb0, 4096); VT_DSR(xb[3], nb0, 6144);
-                if (dma) { piece(ap, bp, cur, 2); piece(ap, bp, cur, 3); }
-                __builtin_amdgcn_sched_barrier(0);
-                VT_ROW6(acc[1], yb, ya[1]);
-                VT_DSR(xb[4], nb0, 8192); VT_DSR(xb[5], nb0, 10240);
-                if (dma) { piece(ap, bp, cur, 4); piece(ap, bp, cur, 5); }
-                __builtin_amdgcn_sched_barrier(0);
-                VT_ROW6(acc[2], yb, ya[2]);
-                VT_DSR(xa[0], na0, 0); VT_DSR(xa[1], na0, 2048);
-                if (dma) { piece(ap, bp, cur, 6); piece(ap, bp, cur, 7); }
-                __builtin_amdgcn_sched_barrier(0);
-                VT_ROW6(acc[3], yb, ya[3]);
-                VT_DSR(xa[2], na0, 4096); VT_DSR(xa[3], na0, 6144);
-                if (dma) { piece(ap, bp, cur, 8); piece(ap, bp, cur, 9); }
-                __builtin_amdgcn_sched_barrier(0);
-                VT_ROW6(acc[4], yb, ya[4]);
-                VT_DSR(xa[4], na0, 8192); VT_DSR(xa[5], na0, 10240);
-                if (dma) { piece(ap, bp, cur, 10); piece(ap, bp, cur, 11); }
-                __builtin_amdgcn_sched_barrier(0);
-                VT_ROW6(acc[5], yb, ya[5]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            slot = nslot;
-        }
-        // prototype epilogue: 8-byte stores from the MFMA layout (the MFMAs are asm: their results need the wait states hipcc would have added)
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int m = m0 + wm * 96 + i * 16 + fr, n = n0 + wn * 96 + j * 16 + fq * 4;
-                f32x4 v = acc[i][j];
-                if (p.bias) v += *(const f32x4*)(p.bias + n);
-                *(bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            }
-    }
-#undef VT_DSR
-#undef VT_ROW6
-}
+// (Round 5 built two more NT kernels on this tile and removed them again after measuring them -- both bit-identical to gemm_nt192_kernel, neither
+// faster: gemm_nt192d_kernel, K = 768 with the epilogue of output tile i inside the K loop of tile i + 1 (k-step register pipeline, a ring that never
+// drains, run-time counted vmcnt, LDS-staged 16-row blocks), and gemm_nt192w4_kernel, four waves of 96 x 96 outputs with the accumulators pinned in
+// AGPRs.  Source: git commit 6dc179d; records: profiles/r05_gemm_deferred_epilogue*.log, r05_gemm_four_wave_prototype.log; DESIGN.md section 5 "Round 5".)
 
 // ------------------------------------------------------------------------------------------------ TN
 struct TN192Args {
@@ -1664,42 +1047,6 @@ int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, in
     return 0;
 }
 
-// The deferred-epilogue kernel (gemm_nt192d_kernel) takes a launch when every output tile lies inside the matrix, K = 768, the epilogue
-// is one of the bf16 ones and the output rows are 8-byte aligned; vt_gemm_nt asks before it falls back to the kernels above.
-bool vt_gemm_nt192d_eligible(const vtGemmNT& p) {
-    return p.K == NT192D_K && p.M % TM == 0 && p.N % TN_ == 0 && p.epi != VT_EPI_F32 && p.ldo % 4 == 0 && ((uintptr_t)p.out & 7) == 0 &&
-           (p.epi != VT_EPI_BF16_GELU || (p.ldo2 % 4 == 0 && ((uintptr_t)p.out2 & 7) == 0)) &&
-           (p.epi != VT_EPI_BF16_DGELU || (p.ldaux % 4 == 0 && ((uintptr_t)p.aux & 7) == 0)) &&
-           (int64_t)TM * p.ldo * 2 < (1ll << 31) && (int64_t)TM * (p.epi == VT_EPI_BF16_GELU ? p.ldo2 : p.epi == VT_EPI_BF16_DGELU ? p.ldaux : 8) * 2 < (1ll << 31);
-}
-int vt_gemm_nt192d_launch(const vtGemmNT& p, hipStream_t s, int one_tile) {
-    NT192Args a;
-    a.p = p;
-    a.dbg = 0;
-    a.tiles_m = p.M / TM;
-    a.tiles_n = p.N / TN_;
-    const int ntiles = a.tiles_m * a.tiles_n;
-    const dim3 grid(one_tile ? ntiles : (ntiles < g_num_cus ? ntiles : g_num_cus)), block(512);
-    const size_t ring = NTGeo<4>::NST * NTGeo<4>::STAGE;
-    switch (p.epi) {
-        case VT_EPI_BF16: hipLaunchKernelGGL((gemm_nt192d_kernel<VT_EPI_BF16>), grid, block, ring + NT192D_EXTRA, s, a); break;
-        case VT_EPI_BF16_GELU: hipLaunchKernelGGL((gemm_nt192d_kernel<VT_EPI_BF16_GELU>), grid, block, ring + NT192D_EXTRA, s, a); break;
-        default: hipLaunchKernelGGL((gemm_nt192d_kernel<VT_EPI_BF16_DGELU>), grid, block, ring + NT192D_EXTRA, s, a); break;
-    }
-    return 0;
-}
-
-int vt_gemm_nt192w4_launch(const vtGemmNT& p, hipStream_t s) {
-    NT192Args a;
-    a.p = p;
-    a.dbg = 0;
-    a.tiles_m = p.M / TM;
-    a.tiles_n = p.N / TN_;
-    const int ntiles = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((gemm_nt192w4_kernel<VT_EPI_BF16>), dim3(ntiles < g_num_cus ? ntiles : g_num_cus), dim3(256), 3 * STAGE_BYTES, s, a);
-    return 0;
-}
-
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst) {
     TN192Args a;
     a.n = n;
@@ -1727,8 +1074,6 @@ extern "C" int vt_gemm_nt_stamps(unsigned long long* host_out) {   // diagnostic
 }
 #endif
 
-int vt_gemm192_num_cus() { return g_num_cus; }
-
 int vt_gemm192_init() {
     // more dynamic LDS than the 64 KiB default: opt in once per kernel
     static bool done = false;
@@ -1742,10 +1087,6 @@ int vt_gemm192_init() {
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_GELU, 2>();
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_F32, 2>();
     if (e == hipSuccess) e = allow_lds_nt<VT_EPI_BF16_DGELU, 2>();
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192d_kernel<VT_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<4>::NST * NTGeo<4>::STAGE + NT192D_EXTRA);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192d_kernel<VT_EPI_BF16_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<4>::NST * NTGeo<4>::STAGE + NT192D_EXTRA);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192d_kernel<VT_EPI_BF16_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, NTGeo<4>::NST * NTGeo<4>::STAGE + NT192D_EXTRA);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt192w4_kernel<VT_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn192p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
     if (e == hipSuccess) {
