@@ -17,6 +17,11 @@ import os
 import sys
 import time
 
+# hipGraph replays of this package's steps need the runtime's graph packet capture off; the runtime reads the flag when the process
+# first touches HIP, so it is set before torch is imported -- the package would set it too, but only at its own import, which comes after
+# torch.cuda.set_device here (it then warns and generation keeps its eager loop)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch
 import torch.distributed as dist
 
