@@ -55,7 +55,22 @@ def _worker(rank, world, port, q):
         ok_mean = torch.allclose(eng.flat_grad[:total], mean[:total], atol=1e-6)
         covered = red.launched[0][0] == 0 and red.launched[-1][1] == total and \
             all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:]))
-        q.put((rank, same, ok_mean, covered, len(red.launched), len(_flat_order(m))))
+        n_full = len(red.launched)
+        # the early release the engine switches on (red.total = elements to come): once less than a bucket is left, every reported slice goes
+        # out at once -- more collectives than with full buckets only, the same tiling of the buffer, the same mean.  (A bucket of 12 M
+        # elements, so that slices have to wait for each other at all: the tiny model's stages are larger than the 1 M-element bucket above.)
+        counts = []
+        for tot in (None, total):
+            eng.flat_grad.copy_(local)
+            red.bucket_elems, red.total = 12_000_000, tot
+            for s in range(nst):
+                red.segment_ready(eng.flat_grad, *eng.segments[s])
+            red.finish()
+            ok_mean = ok_mean and torch.allclose(eng.flat_grad[:total], mean[:total], atol=1e-6)
+            covered = covered and red.launched[0][0] == 0 and red.launched[-1][1] == total and all(a[1] == b[0] for a, b in zip(red.launched, red.launched[1:]))
+            counts.append(len(red.launched))
+        covered = covered and counts[1] > counts[0]
+        q.put((rank, same, ok_mean, covered, n_full, len(_flat_order(m))))
     finally:
         dist.destroy_process_group()
 
