@@ -85,7 +85,9 @@ typedef struct {
                                                 them, else 128x128x64).  Tests / tuning: 1 = force 128, 2 = force 192, 5 = 192x96
                                                 two workgroups per CU, 6 = 192x192 one tile per workgroup, 7 = the M <= 64
                                                 weight-streaming kernel, 8..15 = 192x192 with every other CU starting 1..8 us late
-                                                (timing experiment, correct results), 3/4/17/18 = timing ablations with WRONG results.  Results do not depend on the choice (same fp32
+                                                (timing experiment, correct results), 3/4/17/18 = timing ablations with WRONG results, 19 = 192x192 walking its
+                                                tiles as a row-major list, 19 + W (W = 1..12) = in column blocks of W tile columns (automatic: 6 or 8 when N spans
+                                                at least 6 tiles, else row-major; A/B timing of the order, same results).  Results do not depend on the choice (same fp32
                                                 summation order) unless K is split, below.  The library keeps no such setting between calls */
     void* splitk_ws; int64_t splitk_ws_bytes; /* optional workspace of vt_gemm_nt_splitk_workspace_bytes() bytes, 256-byte aligned, ZERO when first
                                                 handed over (its first 4 KiB are arrival counters the kernel returns to zero) and used by one stream

@@ -27,8 +27,10 @@ __device__ __forceinline__ void glds16_sv(const void* base_uniform, unsigned lan
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // KT = K-tile (64 or 32), DEPTH = K-tiles in flight, SYNC = barrier per K-tile
+// W = 0: tiles in row-major order (the GEMM's); W > 0: column blocks of W tile columns, row-major inside a block, so that an XCD's contiguous
+// chunk of the list is a (chunk / W)-row x W-column rectangle of tiles instead of whole tile rows
 template <int KT, int DEPTH, int SYNC>
-__global__ __launch_bounds__(512, 2) void fill_kernel(const bf16_t* A, const bf16_t* B, int M, int N, int K, int reps, unsigned* sink) {
+__global__ __launch_bounds__(512, 2) void fill_kernel(const bf16_t* A, const bf16_t* B, int M, int N, int K, int reps, unsigned* sink, int W) {
     extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int TM = 192, ROWB = KT * 2;                 // bytes per tile row
     constexpr int OP = TM * ROWB, STAGE = 2 * OP, SLOTS = DEPTH + 1;
@@ -50,8 +52,14 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const bf16_t* A, const bf1
         int g = 0;                                          // running K-tile counter of this workgroup: ring slot = g % SLOTS
         for (int it = blockIdx.x; it < nwg; it += gridDim.x) {
             const int sid = xcd_remap(it, nwg);
-            const bf16_t* Ap = A + (long)(sid / tiles_n) * TM * K;
-            const bf16_t* Bp = B + (long)(sid % tiles_n) * TM * K;
+            int tm = sid / tiles_n, tn = sid % tiles_n;
+            if (W > 0) {
+                const int per = tiles_m * W, b = sid / per, r = sid % per;
+                const int w = (tiles_n - b * W) < W ? (tiles_n - b * W) : W;   // the last block may be narrower
+                tm = r / w, tn = b * W + r % w;
+            }
+            const bf16_t* Ap = A + (long)tm * TM * K;
+            const bf16_t* Bp = B + (long)tn * TM * K;
             for (int t = 0; t < nt; ++t, ++g) {
                 const unsigned dst = sbase + (g % SLOTS) * STAGE;
 #pragma unroll
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const bf16_t* A, const bf1
 }
 
 template <int KT, int DEPTH, int SYNC>
-static void run(const bf16_t* A, const bf16_t* B, int M, int N, int K, unsigned* sink, const char* what) {
+static void run(const bf16_t* A, const bf16_t* B, int M, int N, int K, unsigned* sink, const char* what, int W = 0) {
     constexpr int STAGE = 2 * 192 * KT * 2, SLOTS = DEPTH + 1;
     const size_t lds = (size_t)STAGE * SLOTS;
     if (lds > 160 * 1024) { printf("%-46s skipped (%zu KB of LDS)\n", what, lds / 1024); return; }
@@ -80,9 +88,9 @@ static void run(const bf16_t* A, const bf16_t* B, int M, int N, int K, unsigned*
     const int reps = 20;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((fill_kernel<KT, DEPTH, SYNC>), dim3(256), dim3(512), lds, 0, A, B, M, N, K, reps, sink);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((fill_kernel<KT, DEPTH, SYNC>), dim3(256), dim3(512), lds, 0, A, B, M, N, K, reps, sink, W);
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((fill_kernel<KT, DEPTH, SYNC>), dim3(256), dim3(512), lds, 0, A, B, M, N, K, reps, sink);
+    hipLaunchKernelGGL((fill_kernel<KT, DEPTH, SYNC>), dim3(256), dim3(512), lds, 0, A, B, M, N, K, reps, sink, W);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -94,18 +102,32 @@ static void run(const bf16_t* A, const bf16_t* B, int M, int N, int K, unsigned*
 int main() {
     const int M = 12288, N = 2304, K = 768;
     bf16_t *A, *B; unsigned* sink;
-    CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&B, (size_t)N * K * 2)); CHECK(hipMalloc(&sink, 64));
-    std::vector<unsigned short> h((size_t)M * K);
+    CHECK(hipMalloc(&A, (size_t)M * 3072 * 2)); CHECK(hipMalloc(&B, (size_t)3072 * 3072 * 2)); CHECK(hipMalloc(&sink, 64));
+    std::vector<unsigned short> h((size_t)M * 3072);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x3ff));
-    CHECK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice));
-    CHECK(hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(A, h.data(), (size_t)M * 3072 * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(B, h.data(), (size_t)3072 * 3072 * 2, hipMemcpyHostToDevice));
     printf("# operand staging only, qkv-forward panels (768 output tiles of 192 x 192, 12 K-tiles of 64 each = 453 MB per pass), 256 workgroups x 512 threads\n");
     run<64, 2, 1>(A, B, M, N, K, sink, "K-tile 64, 2 in flight, barrier (the GEMM's)");
+    run<64, 2, 1>(A, B, M, N, K, sink, "  same, column blocks of 6 tiles", 6);
+    run<64, 2, 1>(A, B, M, N, K, sink, "  same, column blocks of 4 tiles", 4);
+    run<64, 2, 1>(A, B, M, N, K, sink, "  same, column blocks of 3 tiles", 3);
+    run<64, 2, 1>(A, B, M, N, K, sink, "  same, column blocks of 2 tiles", 2);
     run<64, 2, 0>(A, B, M, N, K, sink, "K-tile 64, 2 in flight, no barrier");
+    run<64, 2, 0>(A, B, M, N, K, sink, "  same, column blocks of 6 tiles", 6);
     run<64, 1, 1>(A, B, M, N, K, sink, "K-tile 64, 1 in flight, barrier");
     run<32, 2, 1>(A, B, M, N, K, sink, "K-tile 32, 2 in flight, barrier");
     run<32, 4, 1>(A, B, M, N, K, sink, "K-tile 32, 4 in flight, barrier");
     run<32, 5, 1>(A, B, M, N, K, sink, "K-tile 32, 5 in flight, barrier");
     run<32, 5, 0>(A, B, M, N, K, sink, "K-tile 32, 5 in flight, no barrier");
+    printf("# the other shapes of the step (K-tile 64, 2 in flight, barrier); W = tile columns per column block, 0 = row-major\n");
+    const int shapes[][2] = {{3072, 768}, {768, 3072}, {768, 2304}, {768, 768}};
+    for (auto& sh : shapes)
+        for (int W : {0, 2, 4, 6, 8}) {
+            if (W >= sh[0] / 192 && W) continue;
+            char what[96];
+            snprintf(what, sizeof what, "N %4d K %4d W %d", sh[0], sh[1], W);
+            run<64, 2, 1>(A, B, M, sh[0], sh[1], sink, what, W);
+        }
     return 0;
 }

@@ -541,14 +541,14 @@ static void launch_skinny(const vtGemmNT& p, hipStream_t s) {
 constexpr int VT_SPLITK_CTR_BYTES = 4096;   // arrival counters (one per 128x128 output tile) in front of the partial sums
 extern "C" size_t vt_gemm_nt_splitk_workspace_bytes(void) { return VT_SPLITK_CTR_BYTES + (size_t)512 * BM * BN * 4; }   // automatic rule: tiles x split <= 2 x 256
 
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile);
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile, int order);
 int vt_gemm_tn192_launch(const vtGemmTN* ph, int n, hipStream_t s, int burst);
 int vt_gemm192_init();
 extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     const vtGemmNT& p = *ph;
     VT_CHECK_ARG(p.A && p.B && p.out, "vt_gemm_nt: null operand");
     const int g_gemm_variant = p.tile;   // per call (vtGemmNT.tile); the library holds no tile setting of its own
-    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 18, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4/17/18 timing ablations)", g_gemm_variant);
+    VT_CHECK_ARG(g_gemm_variant >= 0 && g_gemm_variant <= 31, "vt_gemm_nt: tile %d (0 auto, 1 = 128x128 2-deep ring, 16 = 128x128 4-deep ring, 2 = 192x192, 5 = 192x96, 6 = 192x192 one tile per workgroup, 7 = skinny M <= 64; 3/4/17/18 timing ablations; 19..31 tile order of the 192x192 kernel)", g_gemm_variant);
     VT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0, "vt_gemm_nt: K=%d must be a positive multiple of 64 (M=%d N=%d)", p.K, p.M, p.N);
     VT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K && p.ldb >= p.K, "vt_gemm_nt: lda/ldb must be >= K and multiples of 8");
     VT_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "vt_gemm_nt: A/B must be 16-byte aligned");
@@ -604,9 +604,11 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     if (big) {
         int rc = vt_gemm192_init();
         if (rc) return rc;
-        const int dbg = (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant >= 17 ? g_gemm_variant - 1 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
+        // 19..31: tile order of the 192x192 kernel for A/B timing (19 = row-major list, 19 + W = column blocks of W tile columns); same results
+        const int order = (g_gemm_variant >= 19 && g_gemm_variant <= 31) ? g_gemm_variant - 19 : -1;
+        const int dbg = order >= 0 ? 0 : (g_gemm_variant == 3 || g_gemm_variant == 4) ? g_gemm_variant - 2 : g_gemm_variant >= 17 ? g_gemm_variant - 1 : g_gemm_variant >= 8 ? g_gemm_variant : 0;
         const int half = g_gemm_variant == 5;
-        vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half, g_gemm_variant == 6);
+        vt_gemm_nt192_launch(p, (hipStream_t)stream, dbg, half, g_gemm_variant == 6, order);
         VT_CHECK_LAUNCH("vt_gemm_nt(192)");
         return VT_OK;
     }

@@ -73,6 +73,7 @@ __device__ __forceinline__ void raw_barrier() {
 struct NT192Args {
     vtGemmNT p;
     int tiles_m, tiles_n;
+    int col_block;  // tile order: 0 = row-major list, W > 0 = column blocks of W tile columns, row-major inside a block (launch_nt192)
     int dbg;      // timing experiments only (vtGemmNT.tile 3/4/17/18): 1 = no LDS-DMA after the prologue, 2 = no MFMA/LDS reads, 16 = no bf16 output stores, 17 = output stores onto a cache-resident region
 };
 
@@ -242,7 +243,13 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     bool poff_full = false;          // poff holds the offsets of a tile that lies fully inside the matrix (no row is clamped): the same for every such tile
     auto set_tile = [&](int it) {
         const int sid = xcd_remap(it, nwg);
-        m0 = (sid / a.tiles_n) * TM, n0 = (sid % a.tiles_n) * G::TNW;
+        int tm = sid / a.tiles_n, tn = sid % a.tiles_n;
+        if (a.col_block > 0) {   // an XCD's contiguous chunk of the list becomes a rectangle of tiles: fewer distinct operand panels among the tiles in flight on its L2
+            const int per = a.tiles_m * a.col_block, b = sid / per, r = sid - b * per;
+            const int left = a.tiles_n - b * a.col_block, w = left < a.col_block ? left : a.col_block;
+            tm = r / w, tn = b * a.col_block + (r - tm * w);
+        }
+        m0 = __builtin_amdgcn_readfirstlane(tm) * TM, n0 = __builtin_amdgcn_readfirstlane(tn) * G::TNW;
         const bool full = m0 + TM <= p.M && n0 + G::TNW <= p.N;
         if (!(full && poff_full)) {
             int tid_s = tid;
@@ -1014,16 +1021,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn192p_kernel(const TN192Args a) 
 }  // namespace
 
 static int g_num_cus = 256;   // set by vt_gemm192_init from the device properties
+static int g_order_env = -1;   // VT_GEMM_TILE_ORDER (read once by vt_gemm192_init): A/B timing of the tile order inside a whole step; -1 = automatic
+
+// Tile order of a launch.  The tile list is dealt to the 8 XCDs in contiguous chunks (xcd_remap); with a row-major list the ~32 tiles in
+// flight on one XCD are 32 / tiles_n whole tile rows, i.e. 32 / tiles_n A panels + ALL tiles_n B panels stream through its 4-MB L2 per round
+// (qkv forward: 2.7 + 12 panels of 295 KB = 4.3 MB, re-fetched every round: FETCH_SIZE 4.4 x the operands).  In column blocks of W tile
+// columns the chunk is a (chunk / W) x W rectangle: 32 / W + W panels per round, least near W = 6, and the W weight panels stay resident
+// from round to round.  Staging alone (tools/probes/fill_probe.hip, profiles/r05_operand_staging_tile_order.log): 19.0 -> 16.6 us and
+// 72 -> 38 MB fetched per pass on qkv forward.  Narrow outputs (tiles_n <= 4) keep the row-major list: every B panel is shared by all rows already.
+static int nt192_auto_col_block(int tiles_m, int tiles_n) {
+    (void)tiles_m;
+    if (tiles_n < 6) return 0;
+    if (tiles_n % 6 == 0) return 6;
+    if (tiles_n % 8 == 0) return 8;
+    return 6;
+}
 
 // Called by vt_gemm_nt / vt_gemm_tn_grouped (vt_gemm.hip) after argument validation.
 template <int WN>
-static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg, int one_tile) {
+static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg, int one_tile, int order) {
     using G = NTGeo<WN>;
     NT192Args a;
     a.p = p;
     a.dbg = dbg;
     a.tiles_m = (p.M + TM - 1) / TM;
     a.tiles_n = (p.N + G::TNW - 1) / G::TNW;
+    if (order < 0) order = g_order_env;
+    a.col_block = order >= 0 ? (order < a.tiles_n ? order : 0) : nt192_auto_col_block(a.tiles_m, a.tiles_n);
     // WN == 4: persistent, one workgroup per CU walks tiles b, b + grid, ...; one_tile (vtGemmNT.tile = 6, the data-parallel backward): one
     // tile per workgroup, so that the hardware dispatcher hands tiles to whichever CU is free while a collective's workgroups hold some.
     // A launch mode, not a timing ablation: `dbg` stays 0 and every epilogue keeps its production store path
@@ -1041,9 +1065,9 @@ static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg, int one_tile
 }
 
 // half == 0: 192x192 tiles, one workgroup per CU; half != 0: 192x96 tiles, two per CU
-int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile) {
-    if (half) launch_nt192<2>(p, s, dbg, one_tile);
-    else launch_nt192<4>(p, s, dbg, one_tile);
+int vt_gemm_nt192_launch(const vtGemmNT& p, hipStream_t s, int dbg, int half, int one_tile, int order) {
+    if (half) launch_nt192<2>(p, s, dbg, one_tile, order);
+    else launch_nt192<4>(p, s, dbg, one_tile, order);
     return 0;
 }
 
@@ -1093,6 +1117,8 @@ int vt_gemm192_init() {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             g_num_cus = cus;
+        const char* ord = getenv("VT_GEMM_TILE_ORDER");
+        if (ord && *ord) g_order_env = atoi(ord);
     }
     if (e != hipSuccess) {
         vt_set_error("vt_gemm192_init: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
