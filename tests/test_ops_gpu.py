@@ -694,3 +694,33 @@ def test_gemm_nt_persistent_walk_equals_one_tile_per_workgroup(hip, K, epi):
         assert torch.equal(outs[2][0].float(), exact.to(torch.bfloat16).float())
     if epi == "f32res":
         assert torch.equal(outs[2][0], exact + res)
+
+
+@pytest.mark.parametrize("M,N", [(192 * 31 + 77, 192 * 17 + 52), (192 * 9 + 1, 192 * 6), (192 * 3, 192 * 12 + 4), (192 * 64, 192 * 7)])
+@pytest.mark.parametrize("epi", ["bf16", "dgelu"])
+def test_gemm_nt_tile_order_does_not_change_the_result(hip, M, N, epi):
+    """the 192x192 kernel walks wide outputs in column blocks of W tile columns (automatic: 6 or 8) instead of as a row-major list: every
+    forced order (vtGemmNT.tile 19 + W, W = 0 .. 12: blocks that divide the tile columns, that leave a narrower last block, that are wider
+    than the matrix), persistent and one tile per workgroup, must visit every tile exactly once -- outputs (and the fused column sums)
+    bit-identical to the row-major walk and equal to exact integer math"""
+    K = 128
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16).cuda()
+    B = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16).cuda()
+    aux = (torch.randint(-6, 7, (M, N), generator=g).float() / 4).to(torch.bfloat16).cuda()
+    kw = dict(epi=hip.EPI_BF16) if epi == "bf16" else dict(epi=hip.EPI_BF16_DGELU, aux=aux)
+    outs = {}
+    try:
+        for v in [19 + w for w in range(13)] + [2, 6]:
+            hip.GEMM_TILE = v
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)     # a tile nobody visits stays NaN
+            part = torch.full(((M + 191) // 192, N), float("nan"), device="cuda") if epi == "dgelu" else None
+            o = hip.gemm_nt(A, B, out=out, colsum_partial=part, **kw)
+            outs[v] = [o.clone()] + ([part] if part is not None else [])
+    finally:
+        hip.GEMM_TILE = 0
+    for v, o in outs.items():
+        for a, b in zip(outs[19], o):
+            assert torch.equal(a, b), v
+    if epi == "bf16":
+        assert torch.equal(outs[19][0].float(), (A.float() @ B.float().t()).to(torch.bfloat16).float())
