@@ -70,7 +70,7 @@ def flops_per_clip(c):
     return 3 * fwd, 3 * attn
 
 
-def time_dominant_kernel(B, c, reps=20):
+def time_dominant_kernel(B, c, reps=50):
     """Roofline of the dominant kernel = the bf16 NT GEMM (gemm_nt_kernel<VT_EPI_BF16>: qkv forward and
     all three input-gradient GEMMs of a block).  Its launches of one training step are replayed through the
     C ABI with the same shapes and timed with HIP events on the stream they run on; achieved = sum of
@@ -86,7 +86,7 @@ def time_dominant_kernel(B, c, reps=20):
         A = torch.randn(m, k, device="cuda").to(torch.bfloat16)
         Bm = (torch.randn(n, k, device="cuda") * 0.03).to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-        for _ in range(3):
+        for _ in range(10):     # the first launches on fresh operands run 5-8 % slow (caches, clocks); the step itself runs them warm
             hip.gemm_nt(A, Bm, hip.EPI_BF16, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
