@@ -175,6 +175,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Tile order of an NT GEMM launch whose tile list is dealt to the XCDs in contiguous chunks (xcd_remap): 0 = row-major list, W > 0 = column blocks
+// of W tile columns, row-major inside a block, so that a chunk is a rectangle of tiles and the tiles in flight on one XCD touch the fewest
+// distinct operand panels (rows + columns of the rectangle; vt_gemm192.hip "Tile order of a launch" has the measurements).  `in_flight` = tiles
+// one XCD works on at a time.  W is the block width nearest sqrt(in_flight) that cuts the tile columns into equal blocks (the last may be narrower).
+static inline int vt_auto_col_block(int tiles_n, int in_flight) {
+    if (tiles_n < 2 || in_flight < 4) return 0;
+    int target = 1;
+    while ((target + 1) * (target + 1) <= in_flight) ++target;            // floor(sqrt(in_flight))
+    if ((target + 1) * (target + 1) - in_flight < in_flight - target * target) ++target;
+    int k = (tiles_n + target / 2) / target;                                // column blocks
+    if (k < 1) k = 1;
+    const int w = (tiles_n + k - 1) / k;
+    return w >= tiles_n ? 0 : w;
+}
+// (tile row, tile column) of list entry `sid` under that order
+__device__ __forceinline__ void vt_tile_of(int sid, int tiles_m, int tiles_n, int col_block, int& tm, int& tn) {
+    tm = sid / tiles_n, tn = sid - tm * tiles_n;
+    if (col_block > 0) {
+        const int per = tiles_m * col_block, b = sid / per, r = sid - b * per;
+        const int left = tiles_n - b * col_block, w = left < col_block ? left : col_block;
+        tm = r / w, tn = b * col_block + (r - tm * w);
+    }
+}
+
 // output row map: r -> (r / grp) * stride + off + (r % grp); grp == 0 means identity
 struct RowMap {
     int grp;

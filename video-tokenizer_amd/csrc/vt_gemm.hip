@@ -13,6 +13,7 @@
 //
 // The MFMA is issued as D' = B_frag x A_frag so that one lane ends up with FOUR CONSECUTIVE OUTPUT
 // COLUMNS of one output row (16 B of fp32 / 8 B of bf16 per store) instead of four rows.
+#include <cstdlib>
 #include "vt_common.h"
 #include "vt_gemm_epilogue.h"
 
@@ -27,6 +28,7 @@ constexpr int TILE_B = BM * BK * 2;  // 16 KiB per operand tile
 struct NTArgs {
     vtGemmNT p;
     int tiles_m, tiles_n;
+    int col_block;      // tile order (vt_tile_of): 0 = row-major list, W = column blocks of W tile columns
     int split;          // workgroups per output tile (split K), 1 = none
     float* part;        // split > 1: fp32 partial tiles, [tile][split][16 acc groups][256 threads] f32x4 (what each lane holds)
     unsigned* ctr;      // split > 1: one arrival counter per tile, zero before and after every launch
@@ -82,8 +84,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTArgs a) {
     // split K: neighbouring workgroups (one XCD) take neighbouring tiles of the SAME K range, so they share operand panels in L2
     const int sid_all = xcd_remap(blockIdx.x, nwg * a.split);
     const int kz = sid_all / nwg, sid = sid_all - kz * nwg;
-    const int tm = sid / a.tiles_n, tn = sid % a.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int tm, tn;
+    vt_tile_of(sid, a.tiles_m, a.tiles_n, a.col_block, tm, tn);
+    const int m0 = __builtin_amdgcn_readfirstlane(tm) * BM, n0 = __builtin_amdgcn_readfirstlane(tn) * BN;
     const int nt_all = p.K / BK;
     const int t_first = (int)((long)kz * nt_all / a.split), nt = (int)((long)(kz + 1) * nt_all / a.split) - t_first;
 
@@ -618,6 +621,7 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     a.tiles_n = (p.N + BN - 1) / BN;
     a.split = 1; a.part = nullptr; a.ctr = nullptr;
     const int tiles = a.tiles_m * a.tiles_n;
+    a.col_block = 0;   // set below, once the number of workgroups per CU is known
     hipStream_t s = (hipStream_t)stream;
     // At most one workgroup per CU (one or two clips per GPU): the 4-deep ring hides the load latency that a co-resident
     // workgroup would otherwise cover (same MFMA order, bit-identical results; tile 16 forces it, tile 1 keeps the 2-deep ring)
@@ -652,6 +656,11 @@ extern "C" int vt_gemm_nt(const vtGemmNT* ph, vtStream stream) {
     }
     const dim3 grid(tiles * a.split), block(256);
     const bool deep = g_gemm_variant == 16 || (g_gemm_variant == 0 && (int)grid.x <= n_cu && nt_all / a.split >= 4);
+    {   // tile order: the tiles one XCD has in flight form a rectangle (vt_common.h); VT_GEMM_TILE_ORDER forces a width for whole-step A/B timing
+        static const int order_env = [] { const char* e = getenv("VT_GEMM_TILE_ORDER"); return (e && *e) ? atoi(e) : -1; }();
+        const int per_xcd = (deep ? 1 : 2) * n_cu / 8, chunk = ((int)grid.x + 7) / 8;
+        a.col_block = order_env >= 0 ? (order_env < a.tiles_n ? order_env : 0) : vt_auto_col_block(a.tiles_n, per_xcd < chunk ? per_xcd : chunk);
+    }
     if (deep) {
         static bool attr_set = false;
         constexpr int LDS4 = 4 * 2 * TILE_B;

@@ -243,12 +243,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
     bool poff_full = false;          // poff holds the offsets of a tile that lies fully inside the matrix (no row is clamped): the same for every such tile
     auto set_tile = [&](int it) {
         const int sid = xcd_remap(it, nwg);
-        int tm = sid / a.tiles_n, tn = sid % a.tiles_n;
-        if (a.col_block > 0) {   // an XCD's contiguous chunk of the list becomes a rectangle of tiles: fewer distinct operand panels among the tiles in flight on its L2
-            const int per = a.tiles_m * a.col_block, b = sid / per, r = sid - b * per;
-            const int left = a.tiles_n - b * a.col_block, w = left < a.col_block ? left : a.col_block;
-            tm = r / w, tn = b * a.col_block + (r - tm * w);
-        }
+        int tm, tn;   // an XCD's contiguous chunk of the list is a rectangle of tiles: fewer distinct operand panels among the tiles in flight on its L2
+        vt_tile_of(sid, a.tiles_m, a.tiles_n, a.col_block, tm, tn);
         m0 = __builtin_amdgcn_readfirstlane(tm) * TM, n0 = __builtin_amdgcn_readfirstlane(tn) * G::TNW;
         const bool full = m0 + TM <= p.M && n0 + G::TNW <= p.N;
         if (!(full && poff_full)) {
@@ -1029,12 +1025,13 @@ static int g_order_env = -1;   // VT_GEMM_TILE_ORDER (read once by vt_gemm192_in
 // columns the chunk is a (chunk / W) x W rectangle: 32 / W + W panels per round, least near W = 6, and the W weight panels stay resident
 // from round to round.  Staging alone (tools/probes/fill_probe.hip, profiles/r05_operand_staging_tile_order.log): 19.0 -> 16.6 us and
 // 72 -> 38 MB fetched per pass on qkv forward.  Narrow outputs (tiles_n <= 4) keep the row-major list: every B panel is shared by all rows already.
-static int nt192_auto_col_block(int tiles_m, int tiles_n) {
-    (void)tiles_m;
-    if (tiles_n < 6) return 0;
-    if (tiles_n % 6 == 0) return 6;
-    if (tiles_n % 8 == 0) return 8;
-    return 6;
+// The width is vt_auto_col_block(tile columns, 32 tiles in flight per XCD): 6 for qkv forward (12 columns) and for N = 3072 (16 columns: 6 + 6 + 4;
+// 6 and 8 measure the same there), row-major for the 4 tile columns of N = 768.
+
+template <int WN>
+static int nt192_in_flight(int ntiles) {   // tiles one XCD works on at a time
+    const int per_xcd = (WN == 4 ? 1 : 2) * g_num_cus / 8, chunk = (ntiles + 7) / 8;
+    return per_xcd < chunk ? per_xcd : chunk;
 }
 
 // Called by vt_gemm_nt / vt_gemm_tn_grouped (vt_gemm.hip) after argument validation.
@@ -1047,7 +1044,7 @@ static void launch_nt192(const vtGemmNT& p, hipStream_t s, int dbg, int one_tile
     a.tiles_m = (p.M + TM - 1) / TM;
     a.tiles_n = (p.N + G::TNW - 1) / G::TNW;
     if (order < 0) order = g_order_env;
-    a.col_block = order >= 0 ? (order < a.tiles_n ? order : 0) : nt192_auto_col_block(a.tiles_m, a.tiles_n);
+    a.col_block = order >= 0 ? (order < a.tiles_n ? order : 0) : vt_auto_col_block(a.tiles_n, nt192_in_flight<WN>(a.tiles_m * a.tiles_n));
     // WN == 4: persistent, one workgroup per CU walks tiles b, b + grid, ...; one_tile (vtGemmNT.tile = 6, the data-parallel backward): one
     // tile per workgroup, so that the hardware dispatcher hands tiles to whichever CU is free while a collective's workgroups hold some.
     // A launch mode, not a timing ablation: `dbg` stays 0 and every epilogue keeps its production store path
