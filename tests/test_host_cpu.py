@@ -490,3 +490,18 @@ def test_fsq_bottleneck_branch_host_surface():
     C, pt, p = 3, cfg["temporal_patch_size"], cfg["patch_size"]
     ref_cols = torch.arange(pt * p * p * C).reshape(pt, p, p, C).permute(3, 0, 1, 2).reshape(-1)      # (c, dt, dy, dx) <- (dt, dy, dx, c)
     assert torch.equal(perm, ref_cols)
+
+
+def test_gemm_tile_order_visits_every_tile_once(tmp_path):
+    """The NT GEMM launchers' tile order (vt_common.h: vt_tile_of / vt_auto_col_block -- column blocks of W tile columns so that an XCD's chunk
+    of the tile list is a rectangle) on the host: every tile grid up to 70 x 26 and every block width is a permutation of the tiles, and the
+    automatic widths are the ones DESIGN quotes.  hipcc compiles the product header for the host; no kernel runs."""
+    import shutil
+    import subprocess
+    from video_tokenizer_amd import build as vt_build
+    if not (shutil.which(vt_build.HIPCC) or os.path.exists(vt_build.HIPCC)):
+        pytest.skip("needs hipcc")
+    exe = str(tmp_path / "tile_order_check")
+    subprocess.check_call([vt_build.HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "c", "tile_order_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout + out.stderr

@@ -190,7 +190,7 @@ static inline int vt_auto_col_block(int tiles_n, int in_flight) {
     return w >= tiles_n ? 0 : w;
 }
 // (tile row, tile column) of list entry `sid` under that order
-__device__ __forceinline__ void vt_tile_of(int sid, int tiles_m, int tiles_n, int col_block, int& tm, int& tn) {
+__host__ __device__ __forceinline__ void vt_tile_of(int sid, int tiles_m, int tiles_n, int col_block, int& tm, int& tn) {
     tm = sid / tiles_n, tn = sid - tm * tiles_n;
     if (col_block > 0) {
         const int per = tiles_m * col_block, b = sid / per, r = sid - b * per;
