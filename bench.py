@@ -515,9 +515,9 @@ def main():
 
     if a.graph:
         # the whole forward + loss + backward as ONE hipGraph replay (engine.GraphedStep); the optimizer step stays outside
-        assert not multi, "--graph: single process only (the gradient reducer is not captured)"
+        # (under the data-parallel wrapper the capture holds the reducer's collectives and stream forks as well; every rank captures here)
         from video_tokenizer_amd.engine import GraphedStep
-        graphed = GraphedStep(model, x, lambda out, xin: (out["pred_frames"] - xin).abs().mean() + 0.1 * out["loss_q"])
+        graphed = GraphedStep(net, x, lambda out, xin: (out["pred_frames"] - xin).abs().mean() + 0.1 * out["loss_q"])
 
         def step():  # noqa: F811
             loss, _ = graphed(x)

@@ -239,9 +239,10 @@ class TokenizerEngine:
         """Data-parallel runs (vt_tokenizer_set_wgrad_stream): the deferred weight-gradient launches and the partial-sum reductions of the same
         blocks run on `stream` (a torch.cuda.Stream, or None for the single-stream schedule) next to the backward's critical path; the engine
         orders both streams with events and joins them at the last stage of backward.  Bit-identical gradients.  Whoever consumes a finished
-        gradient slice before the end of backward (parallel.GradReducer) has to wait for this stream as well.  Not for GraphedStep."""
-        if stream is not None and any(st.graphed for st in self.states.values()):
-            raise RuntimeError("set_wgrad_stream: a geometry of this engine is captured in a hipGraph (GraphedStep); the two-stream schedule is not capturable")
+        gradient slice before the end of backward (parallel.GradReducer) has to wait for this stream as well."""
+        if any(st.graphed for st in self.states.values()) and stream is not self.wgrad_stream:
+            raise RuntimeError("set_wgrad_stream: a geometry of this engine is captured in a hipGraph (GraphedStep) with the schedule it had at "
+                               "capture time; close() the GraphedStep before changing streams")
         self.wgrad_stream = stream
         for st in self.states.values():
             hip.check(hip.lib().vt_tokenizer_set_wgrad_stream(st.handle, stream.cuda_stream if stream is not None else None), "vt_tokenizer_set_wgrad_stream")
@@ -429,7 +430,11 @@ class GraphedStep:
             loss, out = graphed(x)                                # replay; `loss` and the kept outputs are static buffers, valid until the next replay
             opt.step()                                            # do NOT set grads to None in between (zero_grad(set_to_none=False) or nothing)
 
-    Single process only: a data-parallel reducer (parallel.DataParallelTokenizer) is not captured.
+    Under parallel.DataParallelTokenizer (round 5) the capture includes the data-parallel schedule: the stage-by-stage backward, the
+    reducer's event / wait pairs, its RCCL all-reduces on the communication stream (torch's NCCL process group captures its collectives
+    like any other launch) and, when it is on, the side stream of the weight-gradient launches -- every forked stream joins the capturing
+    stream before the backward returns (GradReducer.finish, join_wgrad_stream), which is what stream capture asks for.  Every rank must
+    construct its GraphedStep at the same point and replay in lock-step, like any other collective call.  Pass the wrapper or its .module.
 
     self_check (default on) runs loss_fn for two eager steps and four replays on two clips and requires bit equality, so loss_fn must be a pure
     function of (out, x) and the module's parameters: a loss with state of its own that advances per call (the discriminator's spectral-norm power
@@ -438,13 +443,13 @@ class GraphedStep:
     The check leaves every .grad pointing at the flat buffer's views holding its LAST replay's gradients; the first real replay overwrites them."""
 
     def __init__(self, model, x, loss_fn, warmup=2, outputs=("bottleneck_rep", "loss_q", "loss_commit", "loss_codebook"), self_check=True):
+        if getattr(model, "_engine", None) is None and hasattr(model, "module"):
+            model = model.module                    # a DataParallelTokenizer: its forward is the module's, the reducer hangs on the engine
         eng = model._engine
         if eng is None:
             raise NotImplementedError("GraphedStep needs the fused engine (this model runs on the composed path)")
-        if eng.reducer is not None:
-            raise NotImplementedError("GraphedStep: the data-parallel gradient reducer is not captured; use the eager step under DataParallelTokenizer")
-        if eng.wgrad_stream is not None:
-            raise NotImplementedError("GraphedStep: the two-stream weight-gradient schedule (set_wgrad_stream) is not capturable; call set_wgrad_stream(None) first")
+        if eng.reducer is not None and getattr(eng.reducer, "check_late_writers", False):
+            raise RuntimeError("GraphedStep: GradReducer.check_late_writers synchronises the device at every reported slice and cannot be captured")
         self.model, self.engine, self.loss_fn = model, eng, loss_fn
         from .optim import flatten_parameters
         flatten_parameters(model)       # parameter ADDRESSES are baked into the graph: move them into the flat buffer FusedAdam uses now, not later
