@@ -448,8 +448,9 @@ class GraphedStep:
         eng = model._engine
         if eng is None:
             raise NotImplementedError("GraphedStep needs the fused engine (this model runs on the composed path)")
-        if eng.reducer is not None and getattr(eng.reducer, "check_late_writers", False):
-            raise RuntimeError("GraphedStep: GradReducer.check_late_writers synchronises the device at every reported slice and cannot be captured")
+        if eng.reducer is not None and (getattr(eng.reducer, "check_late_writers", False) or getattr(eng.reducer, "record_events", False)):
+            raise RuntimeError("GraphedStep: GradReducer.check_late_writers (a device-wide synchronisation at every reported slice) and "
+                               "record_events (timing events) are inspection aids of the eager step and cannot be captured; switch them off first")
         self.model, self.engine, self.loss_fn = model, eng, loss_fn
         from .optim import flatten_parameters
         flatten_parameters(model)       # parameter ADDRESSES are baked into the graph: move them into the flat buffer FusedAdam uses now, not later
