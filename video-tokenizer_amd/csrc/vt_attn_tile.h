@@ -165,20 +165,48 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int sp) {
 
 __device__ __forceinline__ int reg_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// store acc^T[d][own_row] tiles (DT x f32x16) as bf16 into dst[own_row][d], 8 B per store
+// store acc^T[d][own_row] tiles (DT x f32x16) as bf16 into dst[own_row][d].  After the 32x32 MFMA chain a row is split over the two
+// half-waves (lane i: columns 8k .. 8k+3, lane i + 32: columns 8k+4 .. 8k+7), so the natural store is 8 bytes per lane and an
+// instruction touches 32 lines with 16 bytes each: the tail is store-ISSUE-bound (guide T21).  v_permlane32_swap exchanges the
+// upper half-wave's group k with the lower one's group k + 1: lanes 0-31 then hold columns 8k .. 8k+7 and lanes 32-63 columns
+// 8k+8 .. 8k+15 of their row -- ONE 16-byte store per pair of groups, same bytes at the same addresses, half the instructions.
+// (every lane takes part in the swaps; `ok` only masks the stores: a row's two lanes are valid or invalid together)
+#ifndef VT_ATTN_STORE8
+#define VT_ATTN_STORE8 0     // A/B diagnostic: 1 = the 8-byte stores of rounds 1-5
+#endif
 template <int DT>
 __device__ __forceinline__ void store_own(const f32x16 (&acc)[DT], float mul, bf16_t* __restrict__ dst, int64_t rs, int row, bool ok, int half) {
-    if (!ok) return;
-    bf16_t* p = dst + (int64_t)row * rs;
+    if constexpr (VT_ATTN_STORE8) {
+        if (!ok) return;
+        bf16_t* p = dst + (int64_t)row * rs;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            bf16x4 v;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[dt][4 * g4 + e] * mul);
-            *(bf16x4*)(p + dt * 32 + 8 * g4 + 4 * half) = v;
-        }
+                for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[dt][4 * g4 + e] * mul);
+                *(bf16x4*)(p + dt * 32 + 8 * g4 + 4 * half) = v;
+            }
+    } else {
+        bf16_t* p = dst + (int64_t)row * rs + 8 * half;      // the upper half-wave writes the next 16 bytes of the row
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                bf16x4 va, vb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    va[e] = f2bf(acc[dt][4 * k + e] * mul);
+                    vb[e] = f2bf(acc[dt][4 * (k + 1) + e] * mul);
+                }
+                u32x2_t a = __builtin_bit_cast(u32x2_t, va), b = __builtin_bit_cast(u32x2_t, vb);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+                if (ok) *(u32x4_t*)(p + dt * 32 + 8 * k) = w;
+            }
+    }
 }
 
 }  // namespace

@@ -56,6 +56,17 @@ constexpr bool kResidualFirst = true;
 
 namespace {
 
+// A/B diagnostic (tools/r05_store_kind_ab.sh): which bf16 outputs of the epilogues leave by ORDINARY instead of streaming (nt) stores.
+// bit 0 = the plain bf16 output (qkv forward, input gradients), bit 1 = the GELU epilogue's u, bit 2 = its g, bit 3 = the gelu' output.
+#ifndef VT_GEMM_PLAIN_STORES
+#define VT_GEMM_PLAIN_STORES 0
+#endif
+template <int BIT, typename T>
+__device__ __forceinline__ void st_out(T* p, const T& v) {
+    if constexpr ((VT_GEMM_PLAIN_STORES >> BIT) & 1) *p = v;
+    else st_stream_any(p, v);
+}
+
 constexpr int TM = 192, TN_ = 192, TK = 64;
 constexpr int OP_BYTES = TM * TK * 2;      // 24 KiB per operand tile (both layouts)
 constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A | B
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                             const bf16x4 uu = uu_pre[it];
                             const bf16x4 r = {f2bf(bf2f(h[0]) * gelu_erf_grad(bf2f(uu[0]))), f2bf(bf2f(h[1]) * gelu_erf_grad(bf2f(uu[1]))),
                                               f2bf(bf2f(h[2]) * gelu_erf_grad(bf2f(uu[2]))), f2bf(bf2f(h[3]) * gelu_erf_grad(bf2f(uu[3])))};
-                            st_stream((bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), r);
+                            st_out<3>((bf16x4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), r);
                             cs += (f32x4){bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
                         }
                     }
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                         const int m = em0 + piece_row(it0 + u), n = en0 + piece_col(it0 + u);
                         if (m >= p.M || n >= p.N) continue;
                         const bf16x8 h = hh[u];
-                        st_stream_any((bf16x8*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), h);
+                        st_out<(EPI == VT_EPI_BF16_GELU ? 1 : 0)>((bf16x8*)((bf16_t*)p.out + (int64_t)m * p.ldo + n), h);
                         if constexpr (EPI == VT_EPI_BF16_GELU) {
                             bf16x8 gl;
                             bool looked_up = false;
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) gl[e] = f2bf(gelu_erf(bf2f(h[e])));
                             }
-                            st_stream_any((bf16x8*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n), gl);
+                            st_out<2>((bf16x8*)((bf16_t*)p.out2 + (int64_t)m * p.ldo2 + n), gl);
                         }
                     }
                 }
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                     const bf16x4 h = hh[u];
                     if (a.dbg == 16 && bf16_bits(h[0]) != 0x7FC1u) continue;          // timing ablation (tile 17): no output stores
                     bf16_t* o = (bf16_t*)p.out + dbg_shift + (int64_t)m * p.ldo + n;
-                    st_stream((bf16x4*)o, h);
+                    st_out<(EPI == VT_EPI_BF16_GELU ? 1 : 0)>((bf16x4*)o, h);
                     if constexpr (EPI == VT_EPI_BF16_GELU) {
                         bf16x4 gl;
                         bool looked_up = false;
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt192_kernel(const NT192Args
                             }
                         }
                         if (!looked_up) gl = (bf16x4){f2bf(gelu_erf(bf2f(h[0]))), f2bf(gelu_erf(bf2f(h[1]))), f2bf(gelu_erf(bf2f(h[2]))), f2bf(gelu_erf(bf2f(h[3])))};
-                        st_stream((bf16x4*)((bf16_t*)p.out2 + dbg_shift + (int64_t)m * p.ldo2 + n), gl);
+                        st_out<2>((bf16x4*)((bf16_t*)p.out2 + dbg_shift + (int64_t)m * p.ldo2 + n), gl);
                     }
                 }
             }
