@@ -186,7 +186,8 @@ int vt_unpatchify(const float* rows, int32_t B, int32_t C, int32_t T, int32_t S,
  * Fused attention, head_dim 64, no mask (timm Attention -> F.scaled_dot_product_attention inside
  * timm Block, models/transformer.py:52-59).  qkv bf16 [B,L,3,H,64]; o/dO bf16 [B,L,H,64];
  * lse2 fp32 [B,H,L] (log2-domain LSE of the scaled scores, saved for backward);
- * delta_ws fp32 [B,H,L] scratch.  Any L >= 1 (tail rows/keys are masked).
+ * delta_ws fp32 [B,H,L] scratch.  Any L >= 1 (tail rows/keys are masked).  qkv, o, dO and dqkv 16-byte aligned (every
+ * operand is read and every output written 16 bytes per lane; a misaligned pointer returns VT_ERR_INVALID).
  * ------------------------------------------------------------------------------------------ */
 int vt_attention_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, void* o, float* lse2, vtStream stream);
 int vt_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse2, int32_t B, int32_t L, int32_t H,

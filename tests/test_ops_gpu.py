@@ -531,6 +531,23 @@ def test_attention_integer_identity(hip, hd):
     np.testing.assert_allclose(o.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
 
 
+def test_attention_refuses_a_misaligned_output(hip):
+    """The attention kernels read and (since the widened stores of round 5) write 16 bytes per lane: an output that is only
+    8-byte aligned must come back as a Python error from the argument check, not reach a kernel."""
+    B, L, H = 1, 128, 2
+    qkv = torch.randn(B * L, 3 * H * 64, device="cuda").to(torch.bfloat16)
+    backing = torch.empty(B * L * H * 64 + 8, device="cuda", dtype=torch.bfloat16)
+    o_bad = backing[4:4 + B * L * H * 64].view(B * L, H * 64)            # 8 bytes past a 16-byte boundary
+    assert o_bad.data_ptr() % 16 == 8
+    with pytest.raises(hip.HipError):
+        hip.attention_fwd(qkv, B, L, H, 64, o=o_bad)
+    o, lse = hip.attention_fwd(qkv, B, L, H, 64)
+    dq_bad = torch.empty(qkv.numel() + 8, device="cuda", dtype=torch.bfloat16)[4:4 + qkv.numel()].view_as(qkv)
+    with pytest.raises(hip.HipError):
+        hip.attention_bwd(qkv, o, torch.randn_like(o), lse, B, L, H, 64, dqkv=dq_bad)
+    torch.cuda.synchronize()
+
+
 # --------------------------------------------------------------------------------------------- VQ
 @pytest.mark.parametrize("case", vq_cases())
 @pytest.mark.parametrize("mode", ["L", "D"])

@@ -619,6 +619,11 @@ static void launch_bwd(const void* qkv, const void* o, const void* dO, const flo
                        delta_ws, (bf16_t*)dqkv, L, H, nblk_k, scale, sl2, q_begin);
 }
 
+// every operand is read and every output written 16 bytes per lane (the outputs since the widened stores of round 5)
+static bool attn_aligned(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
 static int attn_check(const char* who, int B, int L, int H, int hd, int q_begin) {
     VT_CHECK_ARG(hd == 64 || hd == 32, "%s: head_dim %d unsupported (64 or 32)", who, hd);
     VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "%s: bad shape", who);
@@ -629,6 +634,7 @@ static int attn_check(const char* who, int B, int L, int H, int hd, int q_begin)
 extern "C" int vt_attention_fwd_rows(const void* qkv, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t q_begin, void* o_compact, float* lse2,
                                      vtStream stream) {
     VT_CHECK_ARG(qkv && o_compact && lse2, "vt_attention_fwd: null pointer");
+    VT_CHECK_ARG(attn_aligned(qkv, o_compact), "vt_attention_fwd: qkv and o must be 16-byte aligned");
     int rc = attn_check("vt_attention_fwd", B, L, H, hd, q_begin);
     if (rc) return rc;
     if (hd == 64) launch_fwd<64>(qkv, B, L, H, q_begin, o_compact, lse2, (hipStream_t)stream);
@@ -640,6 +646,7 @@ extern "C" int vt_attention_fwd_rows(const void* qkv, int32_t B, int32_t L, int3
 extern "C" int vt_attention_bwd_rows(const void* qkv, const void* o_compact, const void* dO_compact, const float* lse2, int32_t B, int32_t L,
                                      int32_t H, int32_t hd, int32_t q_begin, void* dqkv, float* delta_ws, vtStream stream) {
     VT_CHECK_ARG(qkv && o_compact && dO_compact && lse2 && dqkv && delta_ws, "vt_attention_bwd: null pointer");
+    VT_CHECK_ARG(attn_aligned(qkv, o_compact, dO_compact, dqkv), "vt_attention_bwd: qkv, o, dO and dqkv must be 16-byte aligned");
     int rc = attn_check("vt_attention_bwd", B, L, H, hd, q_begin);
     if (rc) return rc;
     if (hd == 64) launch_bwd<64>(qkv, o_compact, dO_compact, lse2, B, L, H, q_begin, dqkv, delta_ws, (hipStream_t)stream);
@@ -665,6 +672,7 @@ extern "C" int vt_attention_bwd(const void* qkv, const void* o, const void* dO, 
 extern "C" int vt_attention_causal_fwd(const void* qkv, int32_t B, int32_t L, int32_t H, void* o, float* lse2, vtStream stream) {
     VT_CHECK_ARG(qkv && o && lse2, "vt_attention_causal_fwd: null pointer");
     VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_causal_fwd: bad shape");
+    VT_CHECK_ARG(attn_aligned(qkv, o), "vt_attention_causal_fwd: qkv and o must be 16-byte aligned");
     const float sl2 = 0.125f * 1.44269504088896340736f;
     const int nblk = (L + 127) / 128;
     hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(nblk * B * H), dim3(256), 4 * AG<64>::TILE, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o, lse2, L, H,
@@ -677,6 +685,7 @@ extern "C" int vt_attention_causal_bwd(const void* qkv, const void* o, const voi
                                        float* delta_ws, vtStream stream) {
     VT_CHECK_ARG(qkv && o && dO && lse2 && dqkv && delta_ws, "vt_attention_causal_bwd: null pointer");
     VT_CHECK_ARG(B > 0 && L > 0 && H > 0, "vt_attention_causal_bwd: bad shape");
+    VT_CHECK_ARG(attn_aligned(qkv, o, dO, dqkv), "vt_attention_causal_bwd: qkv, o, dO and dqkv must be 16-byte aligned");
     const float scale = 0.125f, sl2 = scale * 1.44269504088896340736f;
     const int nblk = (L + 127) / 128;
     hipStream_t s = (hipStream_t)stream;
