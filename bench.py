@@ -175,14 +175,16 @@ def committed_profile(kind):
     import glob
     for r in (5, 4, 3, 2, 1):
         if kind == "mfma_busy":
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0{r}_pmc_mfma_busy_step*.json"))):
+            # the newest record of a round sorts last (…_step.json < …_step_final_build.json < …_step_second_session.json)
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0{r}_pmc_mfma_busy_step*.json")), reverse=True):
                 with open(path) as f:
                     d = json.load(f)
                 for k in ("whole_step_mfma_pipe_busy", "whole_step_mfma_busy_frac", "whole_step"):
                     if isinstance(d.get(k), (int, float)):
                         return {"value": round(float(d[k]), 4), "source": os.path.relpath(path, ROOT)}
         else:
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0{r}_kernel_stats.csv"))):
+            names = [f"r0{r}_kernel_stats_second_session_final.csv", f"r0{r}_kernel_stats_final_build.csv", f"r0{r}_kernel_stats.csv"]   # newest trace of the round first
+            for path in [q for q in (os.path.join(ROOT, "profiles", n) for n in names) if os.path.exists(q)]:
                 with open(path) as f:
                     for row in csv.DictReader(f):
                         if "gemm_nt192_kernel<0, 4>" in row["Name"]:
