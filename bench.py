@@ -183,7 +183,8 @@ def committed_profile(kind):
                     if isinstance(d.get(k), (int, float)):
                         return {"value": round(float(d[k]), 4), "source": os.path.relpath(path, ROOT)}
         else:
-            names = [f"r0{r}_kernel_stats_second_session_final.csv", f"r0{r}_kernel_stats_final_build.csv", f"r0{r}_kernel_stats.csv"]   # newest trace of the round first
+            # a trace of the step alone (bench.py --no-roofline: no replays of the dominant kernel among its calls) first, then the round's traces of the default command, newest first
+            names = [f"r0{r}_kernel_stats_step_only.csv", f"r0{r}_kernel_stats_second_session_final.csv", f"r0{r}_kernel_stats_final_build.csv", f"r0{r}_kernel_stats.csv"]
             for path in [q for q in (os.path.join(ROOT, "profiles", n) for n in names) if os.path.exists(q)]:
                 with open(path) as f:
                     for row in csv.DictReader(f):
